@@ -1,0 +1,102 @@
+"""ctypes binding of libgat_mi355.so (declarations: include/gat_mi355.h).
+
+The library is the only compute path of this package: if it is missing or a call
+fails, a RuntimeError is raised -- there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgat_mi355.so")
+
+MASK_NONE, MASK_BYTES, MASK_HASH = 0, 1, 2
+
+_i32p = C.POINTER(C.c_int32)
+
+
+class Plan(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("n_split_rows", C.c_int32), ("n_slots", C.c_int32),
+                ("_pad", C.c_int32), ("item_row", C.c_void_p), ("item_beg", C.c_void_p),
+                ("item_slot", C.c_void_p), ("split_row", C.c_void_p), ("split_slot", C.c_void_p)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("num_nodes", C.c_int32), ("num_edges", C.c_int32), ("seg_len", C.c_int32),
+                ("_pad", C.c_int32), ("rowptr", C.c_void_p), ("col", C.c_void_p),
+                ("perm", C.c_void_p), ("rowptr_t", C.c_void_p), ("col_t", C.c_void_p),
+                ("pos_t", C.c_void_p), ("d2s", C.c_void_p), ("plan", Plan), ("plan_t", Plan)]
+
+
+class GraphSizes(C.Structure):
+    _fields_ = [("max_edges", C.c_int64), ("max_items", C.c_int64),
+                ("max_split_rows", C.c_int64), ("workspace_bytes", C.c_int64)]
+
+
+class Shape(C.Structure):
+    _fields_ = [("num_nodes", C.c_int32), ("in_features", C.c_int32), ("heads", C.c_int32),
+                ("channels", C.c_int32)]
+
+
+class Attn(C.Structure):
+    _fields_ = [("shape", Shape), ("negative_slope", C.c_float), ("dropout_p", C.c_float),
+                ("mask_mode", C.c_int32), ("_pad", C.c_int32), ("seed", C.c_uint64),
+                ("mask", C.c_void_p), ("hp", C.c_void_p), ("a_dst", C.c_void_p),
+                ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/gat_mi355.h declares
+SYMBOLS = {
+    "gatmi_last_error": (C.c_char_p, []),
+    "gatmi_version": (C.c_int, []),
+    "gatmi_graph_sizes_query": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                          C.POINTER(GraphSizes)]),
+    "gatmi_graph_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                    C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_project_workspace_bytes": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_project_fwd": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_project_bwd": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_attn_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
+    "gatmi_attn_fwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_dropout_mask": (C.c_int, [C.POINTER(Graph), C.c_int, C.c_float, C.c_uint64, C.c_void_p,
+                                     C.c_void_p]),
+    "gatmi_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
+    "gatmi_attn_bwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile libgat_mi355.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_PKG, "csrc"), "-j4"] + ([] if verbose else ["-s"]),
+                   check=True)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C gat_amd/csrc`).  gat_amd has no fallback path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().gatmi_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {code}): {msg}")

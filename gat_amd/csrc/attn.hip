@@ -1,0 +1,761 @@
+// Fused GAT attention kernels for gfx950: forward (logits + LeakyReLU + segment softmax
+// + attention dropout + aggregation + bias), backward pass A (dst-CSR) and pass B
+// (transposed CSR), the merge kernels for cut rows, and the parameter-gradient column
+// reductions.  Stands for GATConv.forward/backward at /root/reference/gat/model.py:
+// 40,43,46,54.  HBM-bound: each kernel gathers every source
+// (or destination) feature row exactly once, one float4 per lane.
+#include "attn_device.h"
+#include "common.h"
+
+namespace gatmi {
+
+struct RowArgs {
+    // CSR half being walked
+    const int *rowptr;
+    const int *col;
+    const int *aux;        // pass A: d2s
+    const int *item_row;
+    const int *item_beg;
+    const int *item_slot;
+    int n_items;
+    int seg_len;
+    // layer
+    int N, H, C, Cp, Dp, lph2_log;
+    float neg_slope, p_drop, inv_keep;
+    int mask_mode;
+    const uint8_t *mask;
+    uint64_t seed;
+    const float *hp;       // fwd/passA: projected features; passB: padded grad_out
+    const float *a_dst;
+    const float *att_src;
+    const float *att_dst;
+    const float *bias;
+    // fwd
+    float *out;
+    float *lse;
+    float *part_m, *part_s, *part_acc;
+    // passA
+    const float *gout;     // grad_out compact
+    const float *outc;     // forward output (with bias)
+    const float *lse_in;
+    float *gp;             // padded copy of grad_out (NULL when C % 4 == 0)
+    float *rec;            // [E', H, 2] (alpha_tilde, d_u) in transposed-CSR order
+    float *da_dst;         // [N, H]
+    float *part_dad;       // [slots, H]
+    // passB
+    const float *rec_in;
+    const float *da_dst_in;
+    float *dhp;            // [N, Dp]
+    float *da_src;         // [N, H]
+    float *part_das;       // [slots_t, H]
+    float *part_dh;        // [slots_t, Dp]
+};
+
+#define GATMI_ITEM_LOOP_BEGIN                                                             \
+    const int lane = threadIdx.x & 63;                                                    \
+    const int lig = lane & (G - 1);                                                       \
+    const int gbase = lane & ~(G - 1);                                                    \
+    const int lph2 = 1 << A.lph2_log;                                                     \
+    (void)lph2;                                                                           \
+    const Slots<T> S = make_slots<T, G>(lig, A.H, A.C, A.Cp, A.lph2_log);                 \
+    const bool vec_ok = (A.C & 3) == 0;                                                   \
+    constexpr int GPB = 256 / G;                                                          \
+    const int stride = gridDim.x * GPB;                                                   \
+    for (int it = xcd_contiguous_block() * GPB + (int)threadIdx.x / G; it < A.n_items;    \
+         it += stride) {                                                                  \
+        const int row = uniform<G>(A.item_row[it]);                                       \
+        const int beg = uniform<G>(A.item_beg[it]);                                       \
+        const int slot = uniform<G>(A.item_slot[it]);                                     \
+        int end = uniform<G>(A.rowptr[row + 1]);                                          \
+        end = min(end, beg + A.seg_len);
+
+#define GATMI_ITEM_LOOP_END }
+
+// ---------------------------------------------------------------------------------
+// Forward.  Online softmax over the row's edges: the source logit a_src[j] is
+// recomputed from the gathered row (a 4-FMA dot + head butterfly), so the only per-edge
+// HBM traffic is the col index and the feature row itself.
+// ---------------------------------------------------------------------------------
+template <int LPH2_T, int G, int T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
+    constexpr int U = (T == 1) ? 8 : (T == 2 ? 4 : 2);
+    GATMI_ITEM_LOOP_BEGIN
+    float4 att[T], bia[T];
+    float adi[T], m[T], ssum[T];
+    float4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
+        bia[t] = A.bias ? ldc(A.bias + S.coff[t], S.nval[t], vec_ok)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        adi[t] = S.nval[t] ? A.a_dst[(size_t)row * A.H + S.head[t]] : 0.f;
+        m[t] = -INFINITY;
+        ssum[t] = 0.f;
+        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int c = beg; c < end; c += G) {
+        const int n = min(G, end - c);
+        const int cj = (lig < n) ? A.col[c + lig] : 0;
+        for (int k0 = 0; k0 < n; k0 += U) {
+            float4 v[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k0 + u < n;
+                const int j = group_bcast<G>(cj, live ? k0 + u : 0, gbase);
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    v[u][t] = (live && S.nval[t]) ? ld4(A.hp + (size_t)j * A.Dp + S.poff[t])
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float z[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k0 + u < n;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float d = head_sum<LPH2_T>(dot4(v[u][t], att[t]), lph2);
+                    const float uu = d + adi[t];
+                    const float zz = uu > 0.f ? uu : A.neg_slope * uu;
+                    z[u][t] = live ? zz : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float mn = m[t];
+#pragma unroll
+                for (int u = 0; u < U; ++u) mn = fmaxf(mn, z[u][t]);
+                const float sc = expf(m[t] - mn);
+                ssum[t] *= sc;
+                scale4(acc[t], sc);
+                m[t] = mn;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < n) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        float p = expf(z[u][t] - m[t]);
+                        ssum[t] += p;
+                        p *= keep_factor(A.mask_mode, A.mask, A.seed, A.p_drop, A.inv_keep,
+                                         (long long)c + k0 + u, A.H, S.head[t]);
+                        fma4(acc[t], p, v[u][t]);
+                    }
+                }
+            }
+        }
+    }
+    if (slot < 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float inv = ssum[t] > 0.f ? 1.0f / ssum[t] : 0.f;
+            float4 o;
+            o.x = fmaf(acc[t].x, inv, bia[t].x);
+            o.y = fmaf(acc[t].y, inv, bia[t].y);
+            o.z = fmaf(acc[t].z, inv, bia[t].z);
+            o.w = fmaf(acc[t].w, inv, bia[t].w);
+            stc(A.out + (size_t)row * A.H * A.C + S.coff[t], o, S.nval[t], vec_ok);
+            if (A.lse && S.nval[t] && (S.poff[t] % A.Cp) == 0)
+                A.lse[(size_t)row * A.H + S.head[t]] = m[t] + logf(ssum[t]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (S.nval[t]) {
+                st4(A.part_acc + (size_t)slot * A.Dp + S.poff[t], acc[t]);
+                if ((S.poff[t] % A.Cp) == 0) {
+                    A.part_m[(size_t)slot * A.H + S.head[t]] = m[t];
+                    A.part_s[(size_t)slot * A.H + S.head[t]] = ssum[t];
+                }
+            }
+        }
+    }
+    GATMI_ITEM_LOOP_END
+}
+
+// Merge of the partial (m, s, acc) triples of rows that were cut into segments.
+// One wave per cut row; fixed segment order -> bitwise reproducible.
+__global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
+    const int *split_row, const int *split_slot, int n_split, int H, int C, int Cp, int Dp,
+    const float *part_m, const float *part_s, const float *part_acc, const float *bias,
+    float *out, float *lse) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (w >= n_split) return;
+    const int lane = threadIdx.x & 63;
+    const int row = split_row[w], s0 = split_slot[w], s1 = split_slot[w + 1];
+    const int lph = Cp >> 2;
+    for (int q = lane; q < H * lph; q += 64) {
+        const int head = q / lph, sub = q % lph;
+        float M = -INFINITY;
+        for (int s = s0; s < s1; ++s) M = fmaxf(M, part_m[(size_t)s * H + head]);
+        float tot = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = s0; s < s1; ++s) {
+            const float f = expf(part_m[(size_t)s * H + head] - M);
+            tot = fmaf(part_s[(size_t)s * H + head], f, tot);
+            fma4(acc, f, ld4(part_acc + (size_t)s * Dp + head * Cp + sub * 4));
+        }
+        const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+        const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (int k = 0; k < 4; ++k) {
+            const int c = sub * 4 + k;
+            if (c < C) {
+                const float b = bias ? bias[head * C + c] : 0.f;
+                out[(size_t)row * H * C + head * C + c] = fmaf(a4[k], inv, b);
+            }
+        }
+        if (lse && sub == 0) lse[(size_t)row * H + head] = M + logf(tot);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Backward pass A (dst-CSR).  Per edge e = (j -> i):
+//   alpha   = exp(leaky(a_src[j] + a_dst[i]) - lse[i])         (a_src[j] recomputed)
+//   d_at    = <grad_out[i,h,:], h[j,h,:]>
+//   d_u     = (alpha_tilde * d_at - alpha * S_i) * leaky'(u),  S_i = <grad_out[i], out[i] - bias>
+// S_i equals sum_e alpha_e * d_alpha_e because out[i] - bias = sum_e alpha_tilde_e h[j].
+// Writes the record (alpha_tilde, d_u) at the edge's transposed-CSR position, and
+// d a_dst[i] = sum_e d_u.
+// ---------------------------------------------------------------------------------
+template <int LPH2_T, int G, int T>
+__global__ __launch_bounds__(256) void attn_bwd_a_kernel(const RowArgs A) {
+    constexpr int U = (T == 1) ? 8 : (T == 2 ? 4 : 2);
+    GATMI_ITEM_LOOP_BEGIN
+    float4 att[T], g4[T];
+    float adi[T], L[T], Sd[T], dad[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
+        g4[t] = ldc(A.gout + (size_t)row * A.H * A.C + S.coff[t], S.nval[t], vec_ok);
+        float4 o = ldc(A.outc + (size_t)row * A.H * A.C + S.coff[t], S.nval[t], vec_ok);
+        if (A.bias) {
+            const float4 b = ldc(A.bias + S.coff[t], S.nval[t], vec_ok);
+            o.x -= b.x; o.y -= b.y; o.z -= b.z; o.w -= b.w;
+        }
+        Sd[t] = head_sum<LPH2_T>(dot4(g4[t], o), lph2);
+        adi[t] = S.nval[t] ? A.a_dst[(size_t)row * A.H + S.head[t]] : 0.f;
+        L[t] = S.nval[t] ? A.lse_in[(size_t)row * A.H + S.head[t]] : 0.f;
+        dad[t] = 0.f;
+        if (A.gp && S.nval[t] && beg == A.rowptr[row])
+            st4(A.gp + (size_t)row * A.Dp + S.poff[t], g4[t]);
+    }
+    for (int c = beg; c < end; c += G) {
+        const int n = min(G, end - c);
+        const int cj = (lig < n) ? A.col[c + lig] : 0;
+        const int tp = (lig < n) ? A.aux[c + lig] : 0;
+        for (int k0 = 0; k0 < n; k0 += U) {
+            float4 v[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k0 + u < n;
+                const int j = group_bcast<G>(cj, live ? k0 + u : 0, gbase);
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    v[u][t] = (live && S.nval[t]) ? ld4(A.hp + (size_t)j * A.Dp + S.poff[t])
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < n) {
+                    const int tpos = group_bcast<G>(tp, k0 + u, gbase);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const float d1 = head_sum<LPH2_T>(dot4(v[u][t], att[t]), lph2);
+                        const float d2 = head_sum<LPH2_T>(dot4(v[u][t], g4[t]), lph2);
+                        const float uu = d1 + adi[t];
+                        const float zz = uu > 0.f ? uu : A.neg_slope * uu;
+                        const float alpha = expf(zz - L[t]);
+                        const float at = alpha * keep_factor(A.mask_mode, A.mask, A.seed,
+                                                             A.p_drop, A.inv_keep,
+                                                             (long long)c + k0 + u, A.H,
+                                                             S.head[t]);
+                        const float du = (at * d2 - alpha * Sd[t]) * (uu > 0.f ? 1.0f : A.neg_slope);
+                        dad[t] += du;
+                        if (S.nval[t] && (S.poff[t] % A.Cp) == 0)
+                            *reinterpret_cast<float2 *>(
+                                A.rec + ((size_t)tpos * A.H + S.head[t]) * 2) = make_float2(at, du);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (S.nval[t] && (S.poff[t] % A.Cp) == 0) {
+            if (slot < 0)
+                A.da_dst[(size_t)row * A.H + S.head[t]] = dad[t];
+            else
+                A.part_dad[(size_t)slot * A.H + S.head[t]] = dad[t];
+        }
+    }
+    GATMI_ITEM_LOOP_END
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_a_merge_kernel(
+    const int *split_row, const int *split_slot, int n_split, int H, const float *part_dad,
+    float *da_dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_split * H) return;
+    const int w = idx / H, head = idx % H;
+    float acc = 0.f;
+    for (int s = split_slot[w]; s < split_slot[w + 1]; ++s) acc += part_dad[(size_t)s * H + head];
+    da_dst[(size_t)split_row[w] * H + head] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// Backward pass B (transposed CSR).  For source j:
+//   d_h[j] = sum_{e=(j->i)} alpha_tilde_e * grad_out[i]  +  d_a_src[j] att_src + d_a_dst[j] att_dst
+//   d_a_src[j] = sum_e d_u_e
+// Records are read sequentially (pass A wrote them in this order); grad_out rows are
+// gathered from the head-padded copy.
+// ---------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void bwd_b_finish(const RowArgs &A, const Slots<T> &S, bool vec_ok,
+                                             int row, float4 *acc, const float *das) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (S.nval[t]) {
+            const float4 as4 = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
+            const float4 ad4 = ldc(A.att_dst + S.coff[t], S.nval[t], vec_ok);
+            const float dd = A.da_dst_in[(size_t)row * A.H + S.head[t]];
+            float4 o = acc[t];
+            fma4(o, das[t], as4);
+            fma4(o, dd, ad4);
+            st4(A.dhp + (size_t)row * A.Dp + S.poff[t], o);
+            if ((S.poff[t] % A.Cp) == 0) A.da_src[(size_t)row * A.H + S.head[t]] = das[t];
+        }
+    }
+}
+
+template <int G, int T>
+__global__ __launch_bounds__(256) void attn_bwd_b_kernel(const RowArgs A) {
+    constexpr int U = (T == 1) ? 8 : (T == 2 ? 4 : 2);
+    GATMI_ITEM_LOOP_BEGIN
+    float4 acc[T];
+    float das[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        das[t] = 0.f;
+    }
+    for (int c = beg; c < end; c += G) {
+        const int n = min(G, end - c);
+        const int ci = (lig < n) ? A.col[c + lig] : 0;
+        for (int k0 = 0; k0 < n; k0 += U) {
+            float4 v[U][T];
+            float2 r[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k0 + u < n;
+                const int i = group_bcast<G>(ci, live ? k0 + u : 0, gbase);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const bool ok = live && S.nval[t];
+                    v[u][t] = ok ? ld4(A.hp + (size_t)i * A.Dp + S.poff[t])
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    r[u][t] = ok ? *reinterpret_cast<const float2 *>(
+                                       A.rec_in + ((size_t)(c + k0 + u) * A.H + S.head[t]) * 2)
+                                 : make_float2(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    fma4(acc[t], r[u][t].x, v[u][t]);
+                    das[t] += r[u][t].y;
+                }
+            }
+        }
+    }
+    if (slot < 0) {
+        bwd_b_finish<T>(A, S, vec_ok, row, acc, das);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (S.nval[t]) {
+                st4(A.part_dh + (size_t)slot * A.Dp + S.poff[t], acc[t]);
+                if ((S.poff[t] % A.Cp) == 0) A.part_das[(size_t)slot * A.H + S.head[t]] = das[t];
+            }
+        }
+    }
+    GATMI_ITEM_LOOP_END
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_b_merge_kernel(
+    const int *split_row, const int *split_slot, int n_split, int H, int C, int Cp, int Dp,
+    const float *part_dh, const float *part_das, const float *att_src, const float *att_dst,
+    const float *da_dst, float *dhp, float *da_src) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (w >= n_split) return;
+    const int lane = threadIdx.x & 63;
+    const int row = split_row[w], s0 = split_slot[w], s1 = split_slot[w + 1];
+    const int lph = Cp >> 2;
+    for (int q = lane; q < H * lph; q += 64) {
+        const int head = q / lph, sub = q % lph;
+        float das = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = s0; s < s1; ++s) {
+            das += part_das[(size_t)s * H + head];
+            const float4 p = ld4(part_dh + (size_t)s * Dp + head * Cp + sub * 4);
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        const float dd = da_dst[(size_t)row * H + head];
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (int k = 0; k < 4; ++k) {
+            const int c = sub * 4 + k;
+            if (c < C) {
+                o[k] = fmaf(das, att_src[head * C + c], o[k]);
+                o[k] = fmaf(dd, att_dst[head * C + c], o[k]);
+            }
+        }
+        st4(dhp + (size_t)row * Dp + head * Cp + sub * 4, make_float4(o[0], o[1], o[2], o[3]));
+        if (sub == 0) da_src[(size_t)row * H + head] = das;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Parameter gradients: column sums over the N nodes.
+//   d_att_src[h,c] = sum_n d_a_src[n,h] * h[n,h,c]   d_att_dst likewise   d_bias = sum_n grad_out[n]
+// Stage 1: each block sums a stripe of rows into one partial row; stage 2 adds the
+// partial rows in block order (reproducible) and writes the compact [H*C] vectors.
+// ---------------------------------------------------------------------------------
+constexpr int kColsumBlocks = 1024;
+
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(
+    const float *hp, const float *gp, const float *da_src, const float *da_dst, int N, int H,
+    int Cp, int Dp, float *partial /* [blocks, 3, Dp] */) {
+    __shared__ float4 red[3][256];
+    const int nslot = Dp >> 2;  // float4 slots per row, <= 256
+    const int rows_per_pass = 256 / nslot;
+    const int slot = threadIdx.x % nslot;
+    const int rsub = threadIdx.x / nslot;
+    const int head = (slot * 4) / Cp;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, g = a;
+    if (rsub < rows_per_pass) {
+        const long long rows_per_block = ((long long)N + gridDim.x - 1) / gridDim.x;
+        const long long r0 = (long long)blockIdx.x * rows_per_block;
+        const long long r1 = min((long long)N, r0 + rows_per_block);
+        for (long long r = r0 + rsub; r < r1; r += rows_per_pass) {
+            const float4 hv = ld4(hp + r * Dp + slot * 4);
+            const float4 gv = ld4(gp + r * Dp + slot * 4);
+            fma4(a, da_src[r * H + head], hv);
+            fma4(b, da_dst[r * H + head], hv);
+            g.x += gv.x; g.y += gv.y; g.z += gv.z; g.w += gv.w;
+        }
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    red[2][threadIdx.x] = g;
+    __syncthreads();
+    if (threadIdx.x < nslot) {
+        for (int k = 0; k < 3; ++k) {
+            float4 s = red[k][threadIdx.x];
+            for (int q = 1; q < rows_per_pass; ++q) {
+                const float4 o = red[k][threadIdx.x + q * nslot];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            st4(partial + ((size_t)blockIdx.x * 3 + k) * Dp + slot * 4, s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(
+    const float *partial, int nblocks, int H, int C, int Cp, int Dp, float *d_att_src,
+    float *d_att_dst, float *d_bias) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // over 3 * H * C
+    if (idx >= 3 * H * C) return;
+    const int k = idx / (H * C), hc = idx % (H * C);
+    const int pc = (hc / C) * Cp + hc % C;
+    float *dst = k == 0 ? d_att_src : (k == 1 ? d_att_dst : d_bias);
+    if (!dst) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 3 + k) * Dp + pc];
+    dst[hc] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// Host side: shape -> kernel instantiation
+// ---------------------------------------------------------------------------------
+struct Geometry {
+    int Cp, Dp, lph, lph2, lph2_log, G, T;
+};
+
+static int make_geometry(const gatmi_shape &s, Geometry *g) {
+    GATMI_REQUIRE(s.heads >= 1 && s.channels >= 1 && s.num_nodes >= 0 && s.in_features >= 1,
+                  "bad layer shape N=%d F=%d H=%d C=%d", s.num_nodes, s.in_features, s.heads,
+                  s.channels);
+    g->Cp = round_up4(s.channels);
+    g->Dp = s.heads * g->Cp;
+    g->lph = g->Cp / 4;
+    g->lph2 = next_pow2(g->lph);
+    g->lph2_log = ilog2(g->lph2);
+    const int slots = s.heads * g->lph2;
+    if (slots <= 64) {
+        g->G = next_pow2(slots);
+        g->T = 1;
+    } else {
+        g->G = 64;
+        g->T = (slots + 63) / 64;
+        GATMI_REQUIRE(g->T <= 4, "heads*channels too wide: %d x %d (max 1024 padded floats)",
+                      s.heads, s.channels);
+        g->T = g->T == 3 ? 4 : g->T;
+    }
+    GATMI_REQUIRE(g->Dp <= 1024, "heads*round_up(channels,4) = %d exceeds 1024", g->Dp);
+    return GATMI_OK;
+}
+
+enum Kind { FWD, BWD_A, BWD_B };
+
+template <int LPH2_T, int G, int T>
+static void launch_kind(Kind k, const RowArgs &A, int grid, hipStream_t st) {
+    if (k == FWD)
+        hipLaunchKernelGGL((attn_fwd_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
+    else if (k == BWD_A)
+        hipLaunchKernelGGL((attn_bwd_a_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
+    else
+        hipLaunchKernelGGL((attn_bwd_b_kernel<G, T>), dim3(grid), dim3(256), 0, st, A);
+}
+
+static int launch_rows(Kind k, const Geometry &g, const RowArgs &A, hipStream_t st) {
+    if (A.n_items == 0) return GATMI_OK;
+    const int grid = item_grid(A.n_items, 256 / g.G);
+    if (g.G == 64) {
+        if (g.T == 1) {
+            if (g.lph2 == 16) launch_kind<16, 64, 1>(k, A, grid, st);
+            else if (g.lph2 == 8) launch_kind<8, 64, 1>(k, A, grid, st);
+            else launch_kind<0, 64, 1>(k, A, grid, st);
+        } else if (g.T == 2) {
+            if (g.lph2 == 16) launch_kind<16, 64, 2>(k, A, grid, st);
+            else launch_kind<0, 64, 2>(k, A, grid, st);
+        } else {
+            launch_kind<0, 64, 4>(k, A, grid, st);
+        }
+    } else {
+        switch (g.G) {
+            case 32: launch_kind<0, 32, 1>(k, A, grid, st); break;
+            case 16: launch_kind<0, 16, 1>(k, A, grid, st); break;
+            case 8: launch_kind<0, 8, 1>(k, A, grid, st); break;
+            case 4: launch_kind<0, 4, 1>(k, A, grid, st); break;
+            case 2: launch_kind<0, 2, 1>(k, A, grid, st); break;
+            default: launch_kind<0, 1, 1>(k, A, grid, st); break;
+        }
+    }
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+static void fill_common(RowArgs &A, const gatmi_attn &a, const Geometry &g) {
+    memset(&A, 0, sizeof(A));
+    A.N = a.shape.num_nodes;
+    A.H = a.shape.heads;
+    A.C = a.shape.channels;
+    A.Cp = g.Cp;
+    A.Dp = g.Dp;
+    A.lph2_log = g.lph2_log;
+    A.neg_slope = a.negative_slope;
+    A.p_drop = a.dropout_p;
+    A.inv_keep = a.dropout_p < 1.0f ? 1.0f / (1.0f - a.dropout_p) : 0.0f;
+    A.mask_mode = a.mask_mode;
+    A.mask = a.mask;
+    A.seed = a.seed;
+    A.hp = a.hp;
+    A.a_dst = a.a_dst;
+    A.att_src = a.att_src;
+    A.att_dst = a.att_dst;
+    A.bias = a.bias;
+}
+
+static int check_attn(const gatmi_graph *g, const gatmi_attn *a) {
+    GATMI_REQUIRE(g && a, "null graph/attn descriptor");
+    GATMI_REQUIRE(g->num_nodes == a->shape.num_nodes, "graph has %d nodes, layer %d",
+                  g->num_nodes, a->shape.num_nodes);
+    GATMI_REQUIRE(g->seg_len >= 64 && g->seg_len % 64 == 0, "seg_len %d must be a multiple of 64",
+                  g->seg_len);
+    GATMI_REQUIRE(a->mask_mode >= 0 && a->mask_mode <= 2, "bad mask_mode %d", a->mask_mode);
+    GATMI_REQUIRE(a->mask_mode != GATMI_MASK_BYTES || a->mask, "mask_mode BYTES needs a mask");
+    GATMI_REQUIRE(a->dropout_p >= 0.f && a->dropout_p <= 1.f, "dropout_p %f outside [0,1]",
+                  a->dropout_p);
+    GATMI_REQUIRE(a->hp && a->a_dst && a->att_src, "null hp/a_dst/att_src");
+    return GATMI_OK;
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+namespace gatmi {
+__global__ void keep_mask_kernel(uint8_t *out, long long total, int H, uint64_t seed, float p) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = keep_factor(GATMI_MASK_HASH, nullptr, seed, p, 1.0f, i / H, H, (int)(i % H)) != 0.f;
+}
+}  // namespace gatmi
+
+extern "C" int gatmi_dropout_mask(const gatmi_graph *g, int heads, float dropout_p, uint64_t seed,
+                                  uint8_t *mask, void *stream) {
+    GATMI_REQUIRE(g && mask && heads >= 1, "null graph/mask");
+    const long long total = (long long)g->num_edges * heads;
+    if (total == 0) return GATMI_OK;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(keep_mask_kernel, dim3(blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), mask, total, heads, seed, dropout_p);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+extern "C" size_t gatmi_attn_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s) {
+    Geometry geo;
+    if (!g || !s || make_geometry(*s, &geo)) return 0;
+    const size_t slots = (size_t)g->plan.n_slots;
+    return align_up(slots * s->heads * 4) * 2 + align_up(slots * geo.Dp * 4) + 256;
+}
+
+extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *out, float *lse,
+                              void *ws, size_t ws_bytes, void *stream) {
+    if (int e = check_attn(g, a)) return e;
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    GATMI_REQUIRE(out, "null out");
+    if (ws_bytes < gatmi_attn_fwd_workspace_bytes(g, &a->shape)) {
+        set_error("attn_fwd workspace too small: %zu < %zu", ws_bytes,
+                  gatmi_attn_fwd_workspace_bytes(g, &a->shape));
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RowArgs A;
+    fill_common(A, *a, geo);
+    A.rowptr = g->rowptr;
+    A.col = g->col;
+    A.item_row = g->plan.item_row;
+    A.item_beg = g->plan.item_beg;
+    A.item_slot = g->plan.item_slot;
+    A.n_items = g->plan.n_items;
+    A.seg_len = g->seg_len;
+    A.out = out;
+    A.lse = lse;
+    const size_t slots = (size_t)g->plan.n_slots;
+    Carver cv(ws);
+    A.part_m = cv.take<float>(slots * A.H);
+    A.part_s = cv.take<float>(slots * A.H);
+    A.part_acc = cv.take<float>(slots * geo.Dp);
+    if (int e = launch_rows(FWD, geo, A, st)) return e;
+    if (g->plan.n_split_rows > 0) {
+        const int blocks = (g->plan.n_split_rows + 3) / 4;
+        hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(blocks), dim3(256), 0, st,
+                           g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H, A.C,
+                           A.Cp, A.Dp, A.part_m, A.part_s, A.part_acc, A.bias, out, lse);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}
+
+namespace {
+struct BwdWs {
+    float *rec, *gp, *da_dst, *da_src, *part_dad, *part_das, *part_dh, *colsum;
+    size_t bytes;
+};
+BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws) {
+    Carver cv(ws);
+    BwdWs w;
+    const size_t N = (size_t)s->num_nodes, H = (size_t)s->heads;
+    w.rec = cv.take<float>((size_t)g->num_edges * H * 2);
+    w.gp = (s->channels & 3) ? cv.take<float>(N * geo.Dp) : nullptr;
+    w.da_dst = cv.take<float>(N * H);
+    w.da_src = cv.take<float>(N * H);
+    w.part_dad = cv.take<float>((size_t)g->plan.n_slots * H);
+    w.part_das = cv.take<float>((size_t)g->plan_t.n_slots * H);
+    w.part_dh = cv.take<float>((size_t)g->plan_t.n_slots * geo.Dp);
+    w.colsum = cv.take<float>((size_t)kColsumBlocks * 3 * geo.Dp);
+    w.bytes = cv.off + 256;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t gatmi_attn_bwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s) {
+    Geometry geo;
+    if (!g || !s || make_geometry(*s, &geo)) return 0;
+    return carve_bwd(g, s, geo, nullptr).bytes;
+}
+
+extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
+                              const float *lse, const float *grad_out, float *d_hp,
+                              float *d_att_src, float *d_att_dst, float *d_bias, void *ws,
+                              size_t ws_bytes, void *stream) {
+    if (int e = check_attn(g, a)) return e;
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    GATMI_REQUIRE(out && lse && grad_out && d_hp && a->att_dst, "null out/lse/grad_out/d_hp/att_dst");
+    const size_t need = gatmi_attn_bwd_workspace_bytes(g, &a->shape);
+    if (ws_bytes < need) {
+        set_error("attn_bwd workspace too small: %zu < %zu", ws_bytes, need);
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BwdWs w = carve_bwd(g, &a->shape, geo, ws);
+
+    RowArgs A;
+    fill_common(A, *a, geo);
+    A.rowptr = g->rowptr;
+    A.col = g->col;
+    A.aux = g->d2s;
+    A.item_row = g->plan.item_row;
+    A.item_beg = g->plan.item_beg;
+    A.item_slot = g->plan.item_slot;
+    A.n_items = g->plan.n_items;
+    A.seg_len = g->seg_len;
+    A.gout = grad_out;
+    A.outc = out;
+    A.lse_in = lse;
+    A.gp = w.gp;
+    A.rec = w.rec;
+    A.da_dst = w.da_dst;
+    A.part_dad = w.part_dad;
+    if (int e = launch_rows(BWD_A, geo, A, st)) return e;
+    if (g->plan.n_split_rows > 0) {
+        const int tot = g->plan.n_split_rows * A.H;
+        hipLaunchKernelGGL(attn_bwd_a_merge_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
+                           g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H,
+                           w.part_dad, w.da_dst);
+        GATMI_HIP(hipGetLastError());
+    }
+
+    const float *gpad = w.gp ? w.gp : grad_out;
+    RowArgs B;
+    fill_common(B, *a, geo);
+    B.hp = gpad;
+    B.rowptr = g->rowptr_t;
+    B.col = g->col_t;
+    B.item_row = g->plan_t.item_row;
+    B.item_beg = g->plan_t.item_beg;
+    B.item_slot = g->plan_t.item_slot;
+    B.n_items = g->plan_t.n_items;
+    B.seg_len = g->seg_len;
+    B.rec_in = w.rec;
+    B.da_dst_in = w.da_dst;
+    B.dhp = d_hp;
+    B.da_src = w.da_src;
+    B.part_das = w.part_das;
+    B.part_dh = w.part_dh;
+    if (int e = launch_rows(BWD_B, geo, B, st)) return e;
+    if (g->plan_t.n_split_rows > 0) {
+        const int blocks = (g->plan_t.n_split_rows + 3) / 4;
+        hipLaunchKernelGGL(attn_bwd_b_merge_kernel, dim3(blocks), dim3(256), 0, st,
+                           g->plan_t.split_row, g->plan_t.split_slot, g->plan_t.n_split_rows, A.H,
+                           A.C, A.Cp, A.Dp, w.part_dh, w.part_das, a->att_src, a->att_dst,
+                           w.da_dst, d_hp, w.da_src);
+        GATMI_HIP(hipGetLastError());
+    }
+
+    if (d_att_src || d_att_dst || d_bias) {
+        const int N = a->shape.num_nodes;
+        const int blocks = N < kColsumBlocks ? (N > 0 ? N : 1) : kColsumBlocks;
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, gpad,
+                           w.da_src, w.da_dst, N, A.H, A.Cp, A.Dp, w.colsum);
+        GATMI_HIP(hipGetLastError());
+        const int tot = 3 * A.H * A.C;
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
+                           w.colsum, blocks, A.H, A.C, A.Cp, A.Dp, d_att_src, d_att_dst, d_bias);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}

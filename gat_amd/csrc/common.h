@@ -1,0 +1,67 @@
+// Shared host/device helpers for libgat_mi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gat_mi355.h"
+
+namespace gatmi {
+
+void set_error(const char *fmt, ...);
+
+#define GATMI_HIP(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            gatmi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                             __FILE__, __LINE__);                                         \
+            return GATMI_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
+#define GATMI_REQUIRE(cond, ...)                                                          \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            gatmi::set_error(__VA_ARGS__);                                                \
+            return GATMI_ERR_ARG;                                                         \
+        }                                                                                 \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Carves 256-byte aligned pieces out of a caller-provided workspace.
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+    template <class T> T *take(size_t count) {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += align_up(count * sizeof(T));
+        return p;
+    }
+};
+
+inline int round_up4(int c) { return (c + 3) & ~3; }
+inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// Grid for the grid-stride work-item kernels: enough 256-thread blocks to fill
+// 256 CUs x 8 blocks, a multiple of 8 so the XCD remap is a bijection.
+inline int item_grid(long long n_groups_needed, int groups_per_block) {
+    long long blocks = (n_groups_needed + groups_per_block - 1) / groups_per_block;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 8) blocks = 8;
+    return (int)((blocks + 7) / 8 * 8);
+}
+
+}  // namespace gatmi

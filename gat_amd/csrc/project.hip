@@ -1,0 +1,274 @@
+// Head projection h = lin(x) and its backward as fp32-input MFMA GEMMs on gfx950
+// (v_mfma_f32_32x32x2_f32: exact f32 fma chains, so the result is an ordinary fp32
+// GEMM).  Stands for `self.lin(x)` inside GATConv.forward and its autograd backward
+// (call sites /root/reference/gat/model.py:40,43,46,54).
+//
+// One kernel covers the three products through two layout switches:
+//   forward   hp[N,Dp]  = x[N,F]   * Wp[Dp,F]^T      A row-major, B n-major
+//   d_x       dx[N,F]   = dhp[N,Dp]* Wp[Dp,F]        A row-major, B k-major
+//   d_weight  dWp[Dp,F] = dhp[N,Dp]^T * x[N,F]       A k-major,  B k-major, split over N
+// Wp is the weight with each head's rows padded from C to Cp (zero rows), so the output
+// lands directly in the head-padded layout the attention kernels gather from.
+#include "common.h"
+
+namespace gatmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ B, int ldb,
+                                                       float *__restrict__ C, int ldc, int M,
+                                                       int Nn, int K, int k_per_split) {
+    __shared__ float As[BK][LDT];
+    __shared__ float Bs[BK][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    C += (size_t)blockIdx.z * (size_t)M * ldc;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        float ra[8], rb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 256;
+            int m, k;
+            if (A_KMAJOR) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
+            const long long gm = m0 + m;
+            const int gk = k0 + k;
+            const bool ok = gm < M && gk < kend;
+            ra[i] = ok ? (A_KMAJOR ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
+            int n;
+            if (B_KMAJOR) { n = idx % BN; k = idx / BN; } else { k = idx % BK; n = idx / BK; }
+            const int gn = n0 + n;
+            const int gk2 = k0 + k;
+            const bool okb = gn < Nn && gk2 < kend;
+            rb[i] = okb ? (B_KMAJOR ? B[(size_t)gk2 * ldb + gn] : B[(size_t)gn * ldb + gk2]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 256;
+            int m, k;
+            if (A_KMAJOR) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
+            As[k][m] = ra[i];
+            int n;
+            if (B_KMAJOR) { n = idx % BN; k = idx / BN; } else { k = idx % BK; n = idx / BK; }
+            Bs[k][n] = rb[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[kr][wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cn = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long cm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cm < M && cn < Nn) C[(size_t)cm * ldc + cn] = acc[i][j][r];
+            }
+        }
+}
+
+// Wp[(h*Cp + c), f] = c < C ? W[(h*C + c), f] : 0
+__global__ void pad_weight_kernel(const float *w, float *wp, int H, int C, int Cp, int F) {
+    const long long tot = (long long)H * Cp * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const int r = (int)(i / F);
+        const int h = r / Cp, c = r % Cp;
+        wp[i] = c < C ? w[((size_t)h * C + c) * F + f] : 0.f;
+    }
+}
+
+// d_weight[(h*C + c), f] = sum_z slab[z][(h*Cp + c), f]   (fixed order: reproducible)
+__global__ void reduce_dweight_kernel(const float *slab, int nsplit, int H, int C, int Cp, int F,
+                                      float *dw) {
+    const long long tot = (long long)H * C * F;
+    const size_t slab_elems = (size_t)H * Cp * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const int r = (int)(i / F);
+        const int h = r / C, c = r % C;
+        const size_t src = ((size_t)h * Cp + c) * F + f;
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * slab_elems + src];
+        dw[i] = s;
+    }
+}
+
+// a_dst[n,h] = <hp[n,h,:], att_dst[h,:]>.  A block covers R = 256 / (Cp/4) (node, head)
+// groups; every thread moves one float4.
+__global__ __launch_bounds__(256) void row_dots_kernel(const float *hp, const float *att,
+                                                       float *a_dst, long long total_groups,
+                                                       int H, int C, int Cp) {
+    __shared__ float part[256];
+    const int lph = Cp >> 2;
+    const int R = 256 / lph;
+    const long long g0 = (long long)blockIdx.x * R;
+    const int t = threadIdx.x, gl = t / lph, sub = t % lph;
+    const long long grp = g0 + gl;
+    float p = 0.f;
+    if (gl < R && grp < total_groups) {
+        const int head = (int)(grp % H);
+        const float4 v = *reinterpret_cast<const float4 *>(hp + (size_t)grp * Cp + sub * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = sub * 4 + k;
+            if (c < C) p = fmaf(vv[k], att[head * C + c], p);
+        }
+    }
+    part[t] = p;
+    __syncthreads();
+    if (t < R && g0 + t < total_groups) {
+        float s = 0.f;
+        for (int q = 0; q < lph; ++q) s += part[t * lph + q];
+        a_dst[g0 + t] = s;
+    }
+}
+
+static int launch_gemm(bool a_km, bool b_km, const float *A, int lda, const float *B, int ldb,
+                       float *C, int ldc, int M, int Nn, int K, int nsplit, hipStream_t st) {
+    if (M == 0 || Nn == 0) return GATMI_OK;
+    const int kps = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+    dim3 grid((M + BM - 1) / BM, (Nn + BN - 1) / BN, nsplit);
+    if (!a_km && !b_km)
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, A, lda, B, ldb,
+                           C, ldc, M, Nn, K, kps);
+    else if (!a_km && b_km)
+        hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb,
+                           C, ldc, M, Nn, K, kps);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, A, lda, B, ldb,
+                           C, ldc, M, Nn, K, kps);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+static int dweight_splits(int N, int Dp, int F) {
+    const int tiles = ((Dp + BM - 1) / BM) * ((F + BN - 1) / BN);
+    int want = 1024 / tiles;
+    const int maxs = (N + 4 * BK - 1) / (4 * BK);
+    if (want > maxs) want = maxs;
+    return want < 1 ? 1 : want;
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+extern "C" size_t gatmi_project_workspace_bytes(const gatmi_shape *s) {
+    if (!s) return 0;
+    const size_t Cp = round_up4(s->channels), Dp = Cp * s->heads, F = s->in_features;
+    const size_t wp = align_up(Dp * F * 4);
+    const size_t slab = align_up((size_t)dweight_splits(s->num_nodes, (int)Dp, (int)F) * Dp * F * 4);
+    return wp + slab + 256;
+}
+
+static const float *padded_weight(const gatmi_shape *s, const float *weight, float *wp_buf,
+                                  hipStream_t st) {
+    const int C = s->channels, Cp = round_up4(C);
+    if (C == Cp) return weight;
+    const long long tot = (long long)s->heads * Cp * s->in_features;
+    const int blocks = (int)((tot + 255) / 256 > 1024 ? 1024 : (tot + 255) / 256);
+    hipLaunchKernelGGL(pad_weight_kernel, dim3(blocks), dim3(256), 0, st, weight, wp_buf, s->heads,
+                       C, Cp, s->in_features);
+    return wp_buf;
+}
+
+extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const float *weight,
+                                 const float *att_dst, float *hp, float *a_dst, void *ws,
+                                 size_t ws_bytes, void *stream) {
+    GATMI_REQUIRE(s && x && weight && hp, "null argument");
+    GATMI_REQUIRE(s->heads >= 1 && s->channels >= 1 && s->in_features >= 1 && s->num_nodes >= 0,
+                  "bad layer shape");
+    if (ws_bytes < gatmi_project_workspace_bytes(s)) {
+        set_error("project workspace too small: %zu < %zu", ws_bytes,
+                  gatmi_project_workspace_bytes(s));
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int N = s->num_nodes, F = s->in_features, H = s->heads, C = s->channels;
+    const int Cp = round_up4(C), Dp = H * Cp;
+    GATMI_REQUIRE(Cp <= 1024, "channels %d too wide", C);
+    if (N == 0) return GATMI_OK;
+    const float *wp = padded_weight(s, weight, static_cast<float *>(ws), st);
+    GATMI_HIP(hipGetLastError());
+    if (int e = launch_gemm(false, false, x, F, wp, F, hp, Dp, N, Dp, F, 1, st)) return e;
+    if (a_dst) {
+        GATMI_REQUIRE(att_dst, "a_dst requested without att_dst");
+        const int R = 256 / (Cp / 4);
+        const long long groups = (long long)N * H;
+        hipLaunchKernelGGL(row_dots_kernel, dim3((unsigned)((groups + R - 1) / R)), dim3(256), 0,
+                           st, hp, att_dst, a_dst, groups, H, C, Cp);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const float *weight,
+                                 const float *d_hp, float *d_weight, float *d_x, void *ws,
+                                 size_t ws_bytes, void *stream) {
+    GATMI_REQUIRE(s && x && weight && d_hp, "null argument");
+    if (ws_bytes < gatmi_project_workspace_bytes(s)) {
+        set_error("project workspace too small: %zu < %zu", ws_bytes,
+                  gatmi_project_workspace_bytes(s));
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int N = s->num_nodes, F = s->in_features, H = s->heads, C = s->channels;
+    const int Cp = round_up4(C), Dp = H * Cp;
+    float *wp_buf = static_cast<float *>(ws);
+    float *slab = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)Dp * F * 4));
+    if (d_weight) {
+        if (N == 0) {
+            GATMI_HIP(hipMemsetAsync(d_weight, 0, (size_t)H * C * F * 4, st));
+        } else {
+            const int ns = dweight_splits(N, Dp, F);
+            if (int e = launch_gemm(true, true, d_hp, Dp, x, F, slab, F, Dp, F, N, ns, st)) return e;
+            const long long tot = (long long)H * C * F;
+            const int blocks = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+            hipLaunchKernelGGL(reduce_dweight_kernel, dim3(blocks), dim3(256), 0, st, slab, ns, H,
+                               C, Cp, F, d_weight);
+            GATMI_HIP(hipGetLastError());
+        }
+    }
+    if (d_x && N > 0) {
+        const float *wp = padded_weight(s, weight, wp_buf, st);
+        GATMI_HIP(hipGetLastError());
+        if (int e = launch_gemm(false, true, d_hp, Dp, wp, F, d_x, F, N, F, Dp, 1, st)) return e;
+    }
+    return GATMI_OK;
+}

@@ -1,0 +1,164 @@
+/* gat_mi355.h -- C ABI of libgat_mi355.so: the GAT layer hot path on MI355X (gfx950).
+ *
+ * The reference (gokcantali/gat) has no FFI layer of its own: its hot path is the
+ * Python call  GATConv(...)(x, edge_index)  at /root/reference/gat/model.py:26,28,30
+ * (construction) and :40,:43,:46 (forward), differentiated by autograd at :54.  This
+ * header is the boundary a host language binds to replace that call; each entry point
+ * cites the step of that call it stands for (steps as listed in SURVEY.md 8a).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless it says "host";
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*) except
+ *    gatmi_graph_build, which synchronises the stream once to report its counts;
+ *  - no entry point allocates device memory: scratch comes in through `ws`
+ *    (size from the matching *_workspace_bytes query), 256-byte aligned;
+ *  - return value 0 = success; anything else is an error code and
+ *    gatmi_last_error() returns a thread-local message;
+ *  - fp32 values, int32 indices inside the library, int64 edge_index at the door.
+ *
+ * Feature rows live in a head-padded layout: a node's projected features are
+ * H blocks of Cp = round_up(C, 4) floats (pad = 0), Dp = H*Cp floats per node, so that
+ * every head starts on a 16-byte boundary and one lane moves one float4.
+ */
+#ifndef GAT_MI355_H
+#define GAT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATMI_OK 0
+#define GATMI_ERR_ARG 1     /* bad argument / shape */
+#define GATMI_ERR_HIP 2     /* a HIP runtime call failed */
+#define GATMI_ERR_RANGE 3   /* node id outside [0, N) in edge_index */
+#define GATMI_ERR_WS 4      /* workspace too small */
+
+#define GATMI_MASK_NONE 0   /* eval mode / p = 0 */
+#define GATMI_MASK_BYTES 1  /* keep-mask given as bytes [E', H] in dst-CSR edge order */
+#define GATMI_MASK_HASH 2   /* keep-mask derived on the fly from (seed, edge, head) */
+
+const char *gatmi_last_error(void);
+int gatmi_version(void);
+
+/* One half of the graph layout: a CSR over `num_rows` rows plus its segment plan.
+ * Rows longer than seg_len edges are cut into segments; every segment is a work item
+ * (item_row, item_beg); item_slot >= 0 marks a segment of a cut row and names its
+ * partial-result slot, split_row/split_slot list the cut rows for the merge pass. */
+typedef struct gatmi_plan {
+    int32_t n_items;
+    int32_t n_split_rows;
+    int32_t n_slots;
+    int32_t _pad;
+    const int32_t *item_row;   /* [n_items] */
+    const int32_t *item_beg;   /* [n_items] */
+    const int32_t *item_slot;  /* [n_items] */
+    const int32_t *split_row;  /* [n_split_rows] */
+    const int32_t *split_slot; /* [n_split_rows + 1] */
+} gatmi_plan;
+
+/* Destination-sorted CSR with self-loops, and its transpose.
+ * Stands for: remove_self_loops + add_self_loops inside GATConv.forward (SURVEY 8a row
+ * a4; call sites model.py:40,43,46) applied to the edge_index built at
+ * /root/reference/gat/converter.py:12-15, followed by a stable sort by destination.
+ *   rowptr[i]..rowptr[i+1] : in-edges of node i in normalised-list order
+ *   col[e]  : source of edge e          perm[e] : index of e in the normalised list
+ *   rowptr_t/col_t : same edges grouped by source (col_t = destination), ordered by e
+ *   pos_t[t] : dst-CSR position of transposed edge t;   d2s[e] : its inverse        */
+typedef struct gatmi_graph {
+    int32_t num_nodes;
+    int32_t num_edges; /* E' */
+    int32_t seg_len;
+    int32_t _pad;
+    const int32_t *rowptr, *col, *perm;
+    const int32_t *rowptr_t, *col_t, *pos_t, *d2s;
+    gatmi_plan plan;   /* over destination rows */
+    gatmi_plan plan_t; /* over source rows */
+} gatmi_graph;
+
+/* Upper bounds a caller needs to allocate the arrays gatmi_graph_build fills. */
+typedef struct gatmi_graph_sizes {
+    int64_t max_edges;      /* E + N (E when add_self_loops == 0) */
+    int64_t max_items;      /* per plan */
+    int64_t max_split_rows; /* per plan */
+    int64_t workspace_bytes;
+} gatmi_graph_sizes;
+
+int gatmi_graph_sizes_query(int64_t num_edges, int64_t num_nodes, int add_self_loops,
+                            int seg_len, gatmi_graph_sizes *out /* host */);
+
+/* Fills the arrays `g` points to (caller-allocated to the bounds above; the const is
+ * cast away) and sets the counts in *g (host struct).  edge_index: int64 [2, E].
+ * Synchronises `stream` before returning. */
+int gatmi_graph_build(const int64_t *edge_index, int64_t num_edges, int64_t num_nodes,
+                      int add_self_loops, int seg_len, gatmi_graph *g /* host */,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* Shape of one layer.  C = out_channels per head, Cp = round_up(C, 4). */
+typedef struct gatmi_shape {
+    int32_t num_nodes;
+    int32_t in_features;  /* F */
+    int32_t heads;        /* H */
+    int32_t channels;     /* C */
+} gatmi_shape;
+
+/* Projection h = lin(x) into the head-padded layout, plus the
+ * destination logit a_dst[n,h] = <h[n,h,:], att_dst[h,:]> (row a6).  fp32-input MFMA.
+ *   x [N,F]   weight [H*C,F]   att_dst [H*C]   ->   hp [N,Dp]   a_dst [N,H]           */
+size_t gatmi_project_workspace_bytes(const gatmi_shape *s);
+int gatmi_project_fwd(const gatmi_shape *s, const float *x, const float *weight,
+                      const float *att_dst, float *hp, float *a_dst,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* Backward of the projection (row a11, last two formulae): d_weight = d_hp^T x,
+ * d_x = d_hp W (skipped when d_x == NULL).   d_hp [N,Dp] -> d_weight [H*C,F], d_x [N,F] */
+int gatmi_project_bwd(const gatmi_shape *s, const float *x, const float *weight,
+                      const float *d_hp, float *d_weight, float *d_x,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* Arguments of the fused attention kernels. */
+typedef struct gatmi_attn {
+    gatmi_shape shape;
+    float negative_slope;  /* LeakyReLU slope, GATConv default 0.2 */
+    float dropout_p;       /* attention dropout probability (model.py:26,28,30)      */
+    int32_t mask_mode;     /* GATMI_MASK_*                                            */
+    int32_t _pad;
+    uint64_t seed;         /* GATMI_MASK_HASH                                         */
+    const uint8_t *mask;   /* GATMI_MASK_BYTES: [E', H] keep flags, dst-CSR order     */
+    const float *hp;       /* [N, Dp] projected features                              */
+    const float *a_dst;    /* [N, H]                                                  */
+    const float *att_src;  /* [H*C]                                                   */
+    const float *att_dst;  /* [H*C]   (backward only)                                 */
+    const float *bias;     /* [H*C] or NULL                                           */
+} gatmi_attn;
+
+/* Fused logits + LeakyReLU + segment softmax + attention dropout + aggregation + bias
+ * (rows a6-a10): one pass over the dst-CSR, each source row gathered once.
+ *   out [N, H*C];  lse [N, H] = log-sum-exp of the row's logits (NULL when no backward) */
+size_t gatmi_attn_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
+int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *out, float *lse,
+                   void *ws, size_t ws_bytes, void *stream);
+
+/* The keep-mask GATMI_MASK_HASH derives from (seed, edge, head), written out as bytes
+ * [E', H] in dst-CSR order: what F.dropout's Bernoulli draw is to the reference (row a8).
+ * Running GATMI_MASK_BYTES with this mask reproduces the GATMI_MASK_HASH run exactly. */
+int gatmi_dropout_mask(const gatmi_graph *g, int heads, float dropout_p, uint64_t seed,
+                       uint8_t *mask, void *stream);
+
+/* Backward of rows a6-a10 (row a11): pass A over the dst-CSR (softmax/LeakyReLU
+ * gradients, d a_dst), pass B over the transposed CSR (d h gather-accumulate, d a_src),
+ * then the column reductions for d att_src, d att_dst, d bias.
+ *   out, lse : what gatmi_attn_fwd produced;  grad_out [N, H*C]
+ *   -> d_hp [N, Dp], d_att_src [H*C], d_att_dst [H*C], d_bias [H*C] (NULL to skip)     */
+size_t gatmi_attn_bwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
+int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
+                   const float *lse, const float *grad_out, float *d_hp,
+                   float *d_att_src, float *d_att_dst, float *d_bias,
+                   void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAT_MI355_H */

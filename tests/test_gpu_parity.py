@@ -1,0 +1,311 @@
+"""GPU parity tests: the HIP path, called through the C ABI of libgat_mi355.so, against
+the CPU oracle on the same seeded inputs and against the committed golden vectors.
+
+Bars: integer work (graph layout) bit exact; fp32 work within rtol 1e-5 (the tolerance
+BASELINE.json's north_star states) with atol = 1e-5 x the tensor's largest magnitude for
+entries that cancel towards zero.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import gat_oracle as O
+from oracle.csr_ref import build_csr_c
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def close(got, ref, name=""):
+    got = got.detach().cpu()
+    ref = ref.detach().cpu().view_as(got)
+    atol = RTOL * max(float(ref.abs().max()), 1e-30)
+    torch.testing.assert_close(got, ref, rtol=RTOL, atol=atol, msg=lambda m: f"{name}: {m}")
+
+
+# ------------------------------------------------------------------ graph layout
+@pytest.mark.parametrize("gname", list(cases.GRAPHS))
+@pytest.mark.parametrize("asl", [True, False])
+@pytest.mark.parametrize("seg", [64, 512])
+def test_graph_layout_bit_exact(cuda, gname, asl, seg):
+    from gat_amd.graph import build_graph
+    ei, n = cases.GRAPHS[gname]()
+    ref, _ = build_csr_c(ei.numpy(), n, add_self_loops=asl)
+    g = build_graph(ei.to(cuda), n, add_self_loops=asl, seg_len=seg)
+    assert g.num_edges == ref.num_edges
+    for f in ("rowptr", "col", "perm", "rowptr_t", "col_t", "pos_t"):
+        assert np.array_equal(getattr(g, f).cpu().numpy(), getattr(ref, f)), f
+    d2s = g.d2s.cpu().numpy()
+    assert np.array_equal(d2s[ref.pos_t], np.arange(ref.num_edges))
+    # segment plan covers every edge exactly once, in order
+    for plan, rowptr in ((g.desc.plan, ref.rowptr), (g.desc.plan_t, ref.rowptr_t)):
+        pre = "plan" if plan is g.desc.plan else "plan_t"
+        rows = getattr(g, pre + ".item_row")[:plan.n_items].cpu().numpy()
+        begs = getattr(g, pre + ".item_beg")[:plan.n_items].cpu().numpy()
+        slots = getattr(g, pre + ".item_slot")[:plan.n_items].cpu().numpy()
+        covered = np.zeros(ref.num_edges, dtype=np.int32)
+        for r, b in zip(rows, begs):
+            e = min(rowptr[r + 1], b + seg)
+            covered[b:e] += 1
+        assert (covered == 1).all()
+        assert set(rows.tolist()) == set(range(n))
+        deg = np.diff(rowptr)
+        assert plan.n_split_rows == int((deg > seg).sum())
+        assert plan.n_slots == int((slots >= 0).sum())
+
+
+def test_graph_layout_rejects_bad_ids(cuda):
+    from gat_amd.graph import build_graph
+    with pytest.raises(RuntimeError, match="outside"):
+        build_graph(torch.tensor([[0, 9], [1, 0]], device=cuda), 3)
+
+
+def test_graph_layout_large_random(cuda):
+    from gat_amd.graph import build_graph
+    g = torch.Generator().manual_seed(5)
+    n, e = 20000, 300000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[1, :5000] = 7           # a hub
+    ref, _ = build_csr_c(ei.numpy(), n)
+    got = build_graph(ei.to(cuda), n)
+    for f in ("rowptr", "col", "perm", "rowptr_t", "col_t", "pos_t"):
+        assert np.array_equal(getattr(got, f).cpu().numpy(), getattr(ref, f)), f
+
+
+# ------------------------------------------------------------------ projection
+@pytest.mark.parametrize("n,f,h,c", [(300, 25, 8, 30), (1000, 1433, 8, 8), (257, 240, 1, 2),
+                                     (129, 128, 4, 64), (5, 3, 3, 5), (700, 64, 1, 7)])
+def test_projection_fwd_bwd(cuda, n, f, h, c):
+    from gat_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(n + f)
+    x = torch.randn(n, f, generator=g)
+    w = torch.randn(h * c, f, generator=g) / f ** 0.5
+    att = torch.randn(h * c, generator=g)
+    cp = (c + 3) // 4 * 4
+    shape = _lib.Shape(n, f, h, c)
+    xd, wd, ad = x.to(cuda), w.to(cuda), att.to(cuda)
+    hp = torch.full((n, h * cp), float("nan"), device=cuda)
+    a_dst = torch.empty(n, h, device=cuda)
+    ws = torch.empty(lib.gatmi_project_workspace_bytes(C.byref(shape)), dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gatmi_project_fwd(C.byref(shape), xd.data_ptr(), wd.data_ptr(), ad.data_ptr(),
+                                     hp.data_ptr(), a_dst.data_ptr(), ws.data_ptr(), ws.numel(), st), "fwd")
+    href = (x.double() @ w.double().t()).view(n, h, c)
+    got = hp.view(n, h, cp)
+    close(got[:, :, :c], href.float(), "h")
+    assert (got[:, :, c:] == 0).all()
+    close(a_dst, (href * att.double().view(1, h, c)).sum(-1).float(), "a_dst")
+    # backward
+    dh = torch.randn(n, h, cp, generator=g)
+    dh[:, :, c:] = 0
+    dhd = dh.to(cuda).contiguous()
+    dw = torch.empty(h * c, f, device=cuda)
+    dx = torch.empty(n, f, device=cuda)
+    _lib.check(lib.gatmi_project_bwd(C.byref(shape), xd.data_ptr(), wd.data_ptr(), dhd.data_ptr(),
+                                     dw.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd")
+    dhc = dh[:, :, :c].reshape(n, h * c).double()
+    close(dw, (dhc.t() @ x.double()).float(), "d_weight")
+    close(dx, (dhc @ w.double()).float(), "d_x")
+
+
+# ------------------------------------------------------------------ whole layer
+def run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs=None, concat=True):
+    from gat_amd import GATConv
+    x, w, a_s, a_d, b, go = inputs if inputs is not None else cases.layer_inputs(n, f, h, c)
+    conv = GATConv(f, c, heads=h, dropout=p, seg_len=seg).to(cuda)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w)
+        conv.att_src.copy_(a_s)
+        conv.att_dst.copy_(a_d)
+        conv.bias.copy_(b)
+    conv.train(p > 0)
+    conv.injected_mask = mask
+    xd = x.to(cuda).requires_grad_(True)
+    out = conv(xd, ei.to(cuda))
+    out.backward(go.to(cuda))
+    grads = dict(x=xd.grad, weight=conv.lin.weight.grad, att_src=conv.att_src.grad,
+                 att_dst=conv.att_dst.grad, bias=conv.bias.grad)
+    return out, grads
+
+
+LAYER_CASES = [
+    ("knn", "conv1_h30", 0.425, 512), ("knn", "conv3_cls2", 0.425, 512), ("knn", "cora_l1", 0.0, 512),
+    ("multigraph", "conv1_h30", 0.0, 64), ("multigraph", "cora_l2", 0.3, 64),
+    ("multigraph", "three_heads", 0.5, 512), ("multigraph", "wide_t2", 0.2, 64),
+    ("star", "arxiv_h64", 0.4, 64), ("star", "conv1_h30", 0.0, 64), ("star", "cora_l1", 0.3, 64),
+    ("star", "conv3_cls2", 0.0, 64), ("hub_source", "odd_c40", 0.0, 64),
+    ("hub_source", "arxiv_h64", 0.425, 64), ("hub_source", "cora_l2", 0.1, 128),
+    ("chain", "arxiv_h64", 0.0, 512), ("chain", "wide_t2", 0.35, 512), ("empty", "cora_l1", 0.0, 512),
+    ("empty", "arxiv_h64", 0.5, 64),
+]
+
+
+@pytest.mark.parametrize("gname,sname,p,seg", LAYER_CASES)
+def test_layer_matches_oracle(cuda, gname, sname, p, seg):
+    ei, n = cases.GRAPHS[gname]()
+    f, h, c = cases.SHAPES[sname]
+    inputs = cases.layer_inputs(n, f, h, c)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                              mask=mask, training=p > 0)
+    out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs)
+    close(out, ref_out, "out")
+    for k in ref_g:
+        close(g[k], ref_g[k], "d_" + k)
+
+
+def test_layer_error_vs_fp64_is_oracle_sized(cuda):
+    """The HIP result sits as close to the fp64 truth as the fp32 oracle does (x4)."""
+    ei, n = cases.knn_graph(n=400, f=6, seed=3)
+    f, h, c = 25, 8, 30
+    inputs = cases.layer_inputs(n, f, h, c, seed=3)
+    x, w, a_s, a_d, b, go = inputs
+    t64, g64 = O.gatconv_grads_autograd(*[t.double() for t in (x,)], ei, w.double(), a_s.double(),
+                                        a_d.double(), b.double(), h, c, go.double())
+    o32, g32 = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs)
+    def err(a, ref):
+        return float((a.double().cpu().view_as(ref) - ref).abs().max() / ref.abs().max())
+    assert err(out, t64) <= 4 * err(o32, t64) + 1e-7
+    for k in g64:
+        assert err(g[k], g64[k]) <= 4 * err(g32[k], g64[k]) + 1e-7, k
+
+
+def test_no_self_loops_and_no_bias_and_mean_heads(cuda):
+    from gat_amd import GATConv
+    ei, n = cases.random_multigraph()
+    f, h, c = 6, 3, 5
+    x, w, a_s, a_d, _, _ = cases.layer_inputs(n, f, h, c)
+    conv = GATConv(f, c, heads=h, concat=False, add_self_loops=False, bias=False).to(cuda).eval()
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d)
+    out = conv(x.to(cuda), ei.to(cuda))
+    ref = O.gatconv_forward(x, ei, w, a_s, a_d, None, h, c, add_self_loops=False, concat=False)
+    close(out, ref, "out")       # node n-1 has no in-edge at all: its row must be exactly 0
+    assert (out[n - 1] == 0).all()
+
+
+def test_no_grad_and_eval_with_grad(cuda):
+    """model.py:69 runs the layer under no_grad, model.py:130-131 in eval with grad."""
+    from gat_amd import GATConv
+    ei, n = cases.knn_graph()
+    conv = GATConv(5, 4, heads=2, dropout=0.5).to(cuda).eval()
+    x = torch.randn(n, 5, device=cuda)
+    with torch.no_grad():
+        a = conv(x, ei.to(cuda))
+    b = conv(x, ei.to(cuda))
+    assert not a.requires_grad and b.requires_grad
+    assert torch.equal(a, b)
+    b.sum().backward()
+    assert conv.lin.weight.grad is not None
+
+
+def test_hash_dropout_equals_its_own_byte_mask(cuda):
+    """GATMI_MASK_HASH (production dropout) == GATMI_MASK_BYTES fed the materialised mask,
+    bit for bit, forward and backward; keep rate ~ 1 - p."""
+    from gat_amd import GATConv, _lib
+    from gat_amd.graph import cached_graph
+    ei, n = cases.knn_graph(n=500, f=6, seed=2)
+    eid = ei.to(cuda)
+    f, h, c, p = 25, 8, 30, 0.425
+    x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c)
+    layout = cached_graph(eid, n)
+    conv = GATConv(f, c, heads=h, dropout=p).to(cuda).train()
+    torch.manual_seed(11)
+    xd = x.to(cuda).requires_grad_(True)
+    out1 = conv(xd, eid)
+    out1.backward(go.to(cuda))
+    g1 = [xd.grad.clone(), conv.lin.weight.grad.clone(), conv.att_src.grad.clone()]
+    torch.manual_seed(11)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    mask = torch.empty(layout.num_edges, h, dtype=torch.uint8, device=cuda)
+    _lib.check(_lib.lib().gatmi_dropout_mask(layout.ref, h, p, seed, mask.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "mask")
+    rate = float(mask.float().mean())
+    assert abs(rate - (1 - p)) < 0.02
+    # feed it back in normalised-edge order through the test hook
+    norm_mask = torch.empty_like(mask)
+    norm_mask[layout.perm.long()] = mask
+    conv.injected_mask = norm_mask.bool()
+    conv.zero_grad()
+    xd2 = x.to(cuda).requires_grad_(True)
+    out2 = conv(xd2, eid)
+    out2.backward(go.to(cuda))
+    assert torch.equal(out1, out2)
+    assert torch.equal(g1[0], xd2.grad) and torch.equal(g1[1], conv.lin.weight.grad)
+    assert torch.equal(g1[2], conv.att_src.grad)
+
+
+def test_results_are_bitwise_reproducible(cuda):
+    ei, n = cases.star_graph()
+    f, h, c = cases.SHAPES["arxiv_h64"]
+    a = run_layer(cuda, ei, n, f, h, c, 0.0, None, 64)
+    b = run_layer(cuda, ei, n, f, h, c, 0.0, None, 64)
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+
+
+def test_state_dict_round_trip_with_oracle_module(cuda):
+    from gat_amd import GATConv
+    ref = O.OracleGATConv(7, 5, heads=4)
+    conv = GATConv(7, 5, heads=4)
+    conv.load_state_dict(ref.state_dict())
+    conv = conv.to(cuda).eval()
+    ei, n = cases.knn_graph()
+    x = torch.randn(n, 7)
+    close(conv(x.to(cuda), ei.to(cuda)), ref.eval()(x, ei), "out")
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_vectors(cuda, path):
+    from gat_amd.graph import build_graph
+    z = np.load(path)
+    t = lambda k: torch.tensor(z[k])
+    n, h, c, p = int(z["num_nodes"]), int(z["heads"]), int(z["channels"]), float(z["dropout"])
+    ei = t("edge_index")
+    g = build_graph(ei.to(cuda), n)
+    for f in ("rowptr", "col", "perm", "rowptr_t", "col_t", "pos_t"):
+        assert np.array_equal(getattr(g, f).cpu().numpy(), z[f]), f
+    inputs = (t("x"), t("weight"), t("att_src"), t("att_dst"), t("bias"), t("grad_out"))
+    mask = t("mask") if p > 0 else None
+    out, grads = run_layer(cuda, ei, n, inputs[0].size(1), h, c, p, mask, 64, inputs)
+    close(out, t("out"), "out")
+    for k in ("x", "weight", "att_src", "att_dst", "bias"):
+        close(grads[k], t("d_" + k), "d_" + k)
+
+
+# ------------------------------------------------------------------ size-independent properties
+def test_properties_at_scale(cuda):
+    """arxiv-sized random graph (too big for a quick CPU run): softmax weights of every
+    destination sum to one (constant features -> out = const + bias), the layer is linear
+    in grad_out, and node permutation equivariance holds."""
+    from gat_amd import GATConv
+    g = torch.Generator().manual_seed(9)
+    n, e, f, h, c = 169343, 1166243, 128, 4, 64
+    ei = torch.randint(0, n, (2, e), generator=g).to(cuda)
+    conv = GATConv(f, c, heads=h).to(cuda).eval()
+    x = torch.randn(1, f, device=cuda).expand(n, f).contiguous()   # identical rows
+    out = conv(x, ei)
+    expect = (x[:1] @ conv.lin.weight.t()) + conv.bias
+    close(out, expect.expand(n, -1), "constant rows")
+    # linearity of backward in grad_out
+    xr = torch.randn(n, f, device=cuda, requires_grad=True)
+    o = conv(xr, ei)
+    g1 = torch.randn_like(o); g2 = torch.randn_like(o)
+    ga, = torch.autograd.grad(o, xr, g1, retain_graph=True)
+    gb, = torch.autograd.grad(o, xr, g2, retain_graph=True)
+    gc, = torch.autograd.grad(o, xr, g1 + 2 * g2)
+    err = float((ga + 2 * gb - gc).abs().max() / gc.abs().max())
+    assert err < 1e-5, err
