@@ -23,10 +23,14 @@ RTOL = 1e-5
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
-def close(got, ref, name=""):
+def close(got, ref, name="", floor=0.0):
+    """rtol 1e-5, atol 1e-5 x the reference tensor's largest magnitude.  `floor` is a lower
+    bound for that magnitude, used for gradients that are sums of cancelling terms (on a
+    graph with only self-loops d_att_* is exactly 0 in exact arithmetic): there the noise is
+    measured against the size of one summand, |grad_out| * |h|."""
     got = got.detach().cpu()
     ref = ref.detach().cpu().view_as(got)
-    atol = RTOL * max(float(ref.abs().max()), 1e-30)
+    atol = RTOL * max(float(ref.abs().max()), floor, 1e-30)
     torch.testing.assert_close(got, ref, rtol=RTOL, atol=atol, msg=lambda m: f"{name}: {m}")
 
 
@@ -45,8 +49,8 @@ def test_graph_layout_bit_exact(cuda, gname, asl, seg):
     d2s = g.d2s.cpu().numpy()
     assert np.array_equal(d2s[ref.pos_t], np.arange(ref.num_edges))
     # segment plan covers every edge exactly once, in order
-    for plan, rowptr in ((g.desc.plan, ref.rowptr), (g.desc.plan_t, ref.rowptr_t)):
-        pre = "plan" if plan is g.desc.plan else "plan_t"
+    for pre, rowptr in (("plan", ref.rowptr), ("plan_t", ref.rowptr_t)):
+        plan = getattr(g.desc, pre)
         rows = getattr(g, pre + ".item_row")[:plan.n_items].cpu().numpy()
         begs = getattr(g, pre + ".item_beg")[:plan.n_items].cpu().numpy()
         slots = getattr(g, pre + ".item_slot")[:plan.n_items].cpu().numpy()
@@ -160,8 +164,9 @@ def test_layer_matches_oracle(cuda, gname, sname, p, seg):
                                               mask=mask, training=p > 0)
     out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs)
     close(out, ref_out, "out")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
     for k in ref_g:
-        close(g[k], ref_g[k], "d_" + k)
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
 def test_layer_error_vs_fp64_is_oracle_sized(cuda):
@@ -289,8 +294,8 @@ def test_golden_vectors(cuda, path):
 # ------------------------------------------------------------------ size-independent properties
 def test_properties_at_scale(cuda):
     """arxiv-sized random graph (too big for a quick CPU run): softmax weights of every
-    destination sum to one (constant features -> out = const + bias), the layer is linear
-    in grad_out, and node permutation equivariance holds."""
+    destination sum to one (constant features -> out = const + bias), and the backward is
+    linear in grad_out."""
     from gat_amd import GATConv
     g = torch.Generator().manual_seed(9)
     n, e, f, h, c = 169343, 1166243, 128, 4, 64
