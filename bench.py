@@ -1,0 +1,160 @@
+"""bench.py -- GAT layer fwd+bwd edges/sec on MI355X (BASELINE.json's metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|arxiv|cora|runpy100k]
+
+A step is one forward + backward of one GAT layer (projection, fused attention /
+softmax / aggregation, all gradients) over the whole synthetic graph, inputs resident
+in HBM, graph layout built beforehand (one-off, reported separately).  N > 1 is launched
+by torch.distributed.run, one rank per GPU, destination-partitioned (gat_amd/dist.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def kernel_bytes(n, e, h, d):
+    """Algorithmic bytes per launch of the three edge kernels (SURVEY.md 8d split)."""
+    return {
+        "attn_fwd": e * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
+        "attn_bwd_a": e * (4 * d + 8 * h + 4) + n * (4 * d + 12 * h),
+        "attn_bwd_b": e * (4 * d + 8 * h + 8) + n * (4 * d + 4 * h),
+    }
+
+
+def cpu_baseline(name, seed, budget_s=25.0):
+    """The oracle (CPU restatement of the reference's path) timed on this host's cores on
+    a bounded sample of the same workload: the same generator at reduced scale."""
+    from gat_amd import synth
+    from oracle import gat_oracle as O
+    n_full, e_full = synth.WORKLOADS[name][:2]
+    scale = min(1.0, 1.5e6 / e_full)
+    ei, n, f, h, c = synth.workload_graph(name, seed, "cpu", scale)
+    cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    w, a_s, a_d, b = O.init_params(f, h, c, seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, f, generator=g)
+    go = torch.randn(n, h * c, generator=g)
+    ep = ei.size(1) - int((ei[0] == ei[1]).sum()) + n
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
+            break
+    best = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return {"value": ep / best, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{name}-shaped generator at scale {scale:.4f} ({n} nodes, {ep} edges after "
+                      f"self-loop normalisation), oracle/gat_oracle.py fwd+bwd incl. self-loop "
+                      f"normalisation, median of {max(len(times) - 1, 1)} timed runs after 1 warm-up, "
+                      f"torch CPU threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="products")
+    ap.add_argument("--dropout", type=float, default=0.425)  # run.py:21, attention dropout on
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from gat_amd import GATConv, _lib, synth
+    from gat_amd.graph import cached_graph
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from gat_amd.dist import bench_partitioned
+        return bench_partitioned(args, rank, world, dev)
+
+    ei, n, f, h, c = synth.workload_graph(args.workload, args.seed, dev)
+    d = h * c
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    x = torch.randn(n, f, generator=g, device=dev)
+    torch.manual_seed(args.seed)
+    conv = GATConv(f, c, heads=h, dropout=args.dropout).to(dev).train()
+
+    torch.cuda.synchronize()
+    t0 = time.time()
+    layout = cached_graph(ei, n)
+    torch.cuda.synchronize()
+    t_layout = time.time() - t0
+    ep = layout.num_edges
+    go = torch.randn(n, d, generator=g, device=dev)
+
+    def step():
+        conv.zero_grad(set_to_none=True)
+        out = conv(x, ei)
+        out.backward(go)
+
+    for _ in range(args.warmup):
+        step()
+    _lib.prof_read()
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    recs = _lib.prof_read()
+
+    per = {}
+    for tag, ms in recs:
+        per.setdefault(tag, []).append(ms)
+    avg = {k: sum(v) / len(v) for k, v in per.items()}
+    kb = kernel_bytes(n, ep, h, d)
+    dom = max(kb, key=lambda k: avg.get(k, 0.0))
+    achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom]}
+    kernels = {k: {"avg_ms": round(v, 4),
+                   **({"alg_GBps": round(kb[k] / (v * 1e-3) / 1e9, 1)} if k in kb else {})}
+               for k, v in sorted(avg.items())}
+
+    ms_step = elapsed / args.steps * 1e3
+    res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
+           "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
+                                  f"{ei.size(1)} edges ({ep} after self-loop normalisation), "
+                                  f"one GAT layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
+                      "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
+                      "parallelism": "single GPU", "graph_layout_build_s": round(t_layout, 4)},
+           "roofline": roofline, "kernels": kernels}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

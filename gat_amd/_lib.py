@@ -51,6 +51,8 @@ class Attn(C.Structure):
 SYMBOLS = {
     "gatmi_last_error": (C.c_char_p, []),
     "gatmi_version": (C.c_int, []),
+    "gatmi_prof_enable": (C.c_int, [C.c_int]),
+    "gatmi_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     "gatmi_graph_sizes_query": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int,
                                           C.POINTER(GraphSizes)]),
     "gatmi_graph_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
@@ -100,3 +102,16 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = lib().gatmi_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {code}): {msg}")
+
+
+def prof_enable(on: bool) -> None:
+    lib().gatmi_prof_enable(int(on))
+
+
+def prof_read(max_records: int = 65536):
+    """-> list of (kernel tag, milliseconds) recorded since the last read."""
+    tags = C.create_string_buffer(max_records * 32)
+    ms = (C.c_float * max_records)()
+    n = lib().gatmi_prof_read(tags, ms, max_records)
+    raw = tags.raw
+    return [(raw[i * 32:(i + 1) * 32].split(b"\0", 1)[0].decode(), float(ms[i])) for i in range(n)]

@@ -638,8 +638,12 @@ extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *
     A.part_m = cv.take<float>(slots * A.H);
     A.part_s = cv.take<float>(slots * A.H);
     A.part_acc = cv.take<float>(slots * geo.Dp);
-    if (int e = launch_rows(FWD, geo, A, st)) return e;
+    {
+        ProfScope ps("attn_fwd", st);
+        if (int e = launch_rows(FWD, geo, A, st)) return e;
+    }
     if (g->plan.n_split_rows > 0) {
+        ProfScope ps("attn_fwd_merge", st);
         const int blocks = (g->plan.n_split_rows + 3) / 4;
         hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(blocks), dim3(256), 0, st,
                            g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H, A.C,
@@ -710,8 +714,12 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     A.rec = w.rec;
     A.da_dst = w.da_dst;
     A.part_dad = w.part_dad;
-    if (int e = launch_rows(BWD_A, geo, A, st)) return e;
+    {
+        ProfScope ps("attn_bwd_a", st);
+        if (int e = launch_rows(BWD_A, geo, A, st)) return e;
+    }
     if (g->plan.n_split_rows > 0) {
+        ProfScope ps("attn_bwd_a_merge", st);
         const int tot = g->plan.n_split_rows * A.H;
         hipLaunchKernelGGL(attn_bwd_a_merge_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
                            g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H,
@@ -736,8 +744,12 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     B.da_src = w.da_src;
     B.part_das = w.part_das;
     B.part_dh = w.part_dh;
-    if (int e = launch_rows(BWD_B, geo, B, st)) return e;
+    {
+        ProfScope ps("attn_bwd_b", st);
+        if (int e = launch_rows(BWD_B, geo, B, st)) return e;
+    }
     if (g->plan_t.n_split_rows > 0) {
+        ProfScope ps("attn_bwd_b_merge", st);
         const int blocks = (g->plan_t.n_split_rows + 3) / 4;
         hipLaunchKernelGGL(attn_bwd_b_merge_kernel, dim3(blocks), dim3(256), 0, st,
                            g->plan_t.split_row, g->plan_t.split_slot, g->plan_t.n_split_rows, A.H,
@@ -747,6 +759,7 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     }
 
     if (d_att_src || d_att_dst || d_bias) {
+        ProfScope ps("param_colsum", st);
         const int N = a->shape.num_nodes;
         const int blocks = N < kColsumBlocks ? (N > 0 ? N : 1) : kColsumBlocks;
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, gpad,

@@ -29,6 +29,16 @@ void set_error(const char *fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Optional per-kernel timing with HIP events on the launch stream (off by default);
+// see gatmi_prof_enable / gatmi_prof_read.
+void prof_begin(const char *tag, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st;
+    ProfScope(const char *tag, hipStream_t s) : st(s) { prof_begin(tag, s); }
+    ~ProfScope() { prof_end(st); }
+};
+
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // Carves 256-byte aligned pieces out of a caller-provided workspace.

@@ -1,6 +1,9 @@
 // Thread-local error message and version of libgat_mi355.so.
 #include <stdarg.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace gatmi {
@@ -11,7 +14,54 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+struct ProfRec {
+    char tag[32];
+    hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+void prof_begin(const char *tag, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    snprintf(r.tag, sizeof(r.tag), "%s", tag);
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, st);
+}
 }  // namespace gatmi
+
+extern "C" int gatmi_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(gatmi::g_prof_mu);
+    gatmi::g_prof_on = on != 0;
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_prof_read(char *tags, float *ms, int max_records) {
+    std::lock_guard<std::mutex> lk(gatmi::g_prof_mu);
+    int n = 0;
+    for (auto &r : gatmi::g_prof) {
+        float t = -1.f;
+        if (hipEventSynchronize(r.b) == hipSuccess) (void)hipEventElapsedTime(&t, r.a, r.b);
+        if (n < max_records && tags && ms) {
+            memcpy(tags + (size_t)n * 32, r.tag, 32);
+            ms[n] = t;
+            ++n;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    gatmi::g_prof.clear();
+    return n;
+}
 
 extern "C" const char *gatmi_last_error(void) { return gatmi::g_err; }
 extern "C" int gatmi_version(void) { return 100; }

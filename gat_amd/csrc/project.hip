@@ -226,8 +226,12 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
     if (N == 0) return GATMI_OK;
     const float *wp = padded_weight(s, weight, static_cast<float *>(ws), st);
     GATMI_HIP(hipGetLastError());
-    if (int e = launch_gemm(false, false, x, F, wp, F, hp, Dp, N, Dp, F, 1, st)) return e;
+    {
+        ProfScope ps("proj_fwd_gemm", st);
+        if (int e = launch_gemm(false, false, x, F, wp, F, hp, Dp, N, Dp, F, 1, st)) return e;
+    }
     if (a_dst) {
+        ProfScope ps("proj_row_dots", st);
         GATMI_REQUIRE(att_dst, "a_dst requested without att_dst");
         const int R = 256 / (Cp / 4);
         const long long groups = (long long)N * H;
@@ -256,6 +260,7 @@ extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const flo
         if (N == 0) {
             GATMI_HIP(hipMemsetAsync(d_weight, 0, (size_t)H * C * F * 4, st));
         } else {
+            ProfScope ps("proj_bwd_w_gemm", st);
             const int ns = dweight_splits(N, Dp, F);
             if (int e = launch_gemm(true, true, d_hp, Dp, x, F, slab, F, Dp, F, N, ns, st)) return e;
             const long long tot = (long long)H * C * F;
@@ -268,6 +273,7 @@ extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const flo
     if (d_x && N > 0) {
         const float *wp = padded_weight(s, weight, wp_buf, st);
         GATMI_HIP(hipGetLastError());
+        ProfScope ps("proj_bwd_x_gemm", st);
         if (int e = launch_gemm(false, true, d_hp, Dp, wp, F, d_x, F, N, F, Dp, 1, st)) return e;
     }
     return GATMI_OK;

@@ -1,0 +1,52 @@
+"""Synthetic graphs of the shapes BASELINE.json names: power-law
+in-degree, uniform sources, no datasets needed.  Generated on whatever device the
+generator lives on, deterministically from the seed."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+# name -> (nodes, edges, in_features, heads, channels, max in-degree aimed for)
+WORKLOADS = {
+    "cora": (2708, 10556, 1433, 8, 8, 170),
+    "arxiv": (169343, 1166243, 128, 4, 64, 13000),
+    "products": (2449029, 62000000, 100, 4, 64, 17000),
+    "runpy100k": (100000, 500000, 25, 8, 30, 0),
+}
+
+
+def powerlaw_graph(num_nodes: int, num_edges: int, max_degree: int, seed: int = 0,
+                   device="cpu") -> torch.Tensor:
+    """edge_index int64 [2, E]: src uniform; dst = perm[floor(N * u**gamma)], gamma chosen
+    so the heaviest destination collects about `max_degree` edges (0: uniform dst)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    src = torch.randint(0, num_nodes, (num_edges,), generator=g, device=device)
+    if max_degree and max_degree * num_nodes > num_edges:
+        inv_gamma = math.log(num_edges / max_degree) / math.log(num_nodes)
+        gamma = 1.0 / max(inv_gamma, 1e-3)
+        u = torch.rand(num_edges, generator=g, device=device, dtype=torch.float64)
+        idx = (u.pow(gamma) * num_nodes).long().clamp_(max=num_nodes - 1)
+        perm = torch.randperm(num_nodes, generator=g, device=device)
+        dst = perm[idx]
+    else:
+        dst = torch.randint(0, num_nodes, (num_edges,), generator=g, device=device)
+    return torch.stack([src, dst])
+
+
+def out_degree_k_graph(num_nodes: int, k: int = 5, seed: int = 0, device="cpu") -> torch.Tensor:
+    """The shape /root/reference/gat/converter.py:7-15 emits: every node sends to k
+    others (first neighbour = itself, as include_self=True usually yields)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    src = torch.arange(num_nodes, device=device).repeat_interleave(k)
+    dst = torch.randint(0, num_nodes, (num_nodes, k), generator=g, device=device)
+    dst[:, 0] = torch.arange(num_nodes, device=device)
+    return torch.stack([src, dst.reshape(-1)])
+
+
+def workload_graph(name: str, seed: int = 0, device="cpu", scale: float = 1.0):
+    n, e, f, h, c, dmax = WORKLOADS[name]
+    n, e = max(int(n * scale), 8), max(int(e * scale), 8)
+    if name.startswith("runpy"):
+        return out_degree_k_graph(n, 5, seed, device), n, f, h, c
+    return powerlaw_graph(n, e, int(dmax * max(scale, 0.05)) if dmax else 0, seed, device), n, f, h, c

@@ -43,6 +43,15 @@ extern "C" {
 const char *gatmi_last_error(void);
 int gatmi_version(void);
 
+/* Per-kernel timing for benchmarks (no counterpart in the reference, which only prints
+ * epoch wall time at model.py:89,105): while enabled, every kernel the library launches
+ * is bracketed by HIP events on its launch stream.  gatmi_prof_read waits for the
+ * recorded events, copies up to max_records (tag[32], milliseconds) pairs out (host
+ * pointers), clears the list and returns the number copied. */
+int gatmi_prof_enable(int on);
+int gatmi_prof_read(char *tags /* host [max_records][32] */, float *ms /* host */,
+                    int max_records);
+
 /* One half of the graph layout: a CSR over `num_rows` rows plus its segment plan.
  * Rows longer than seg_len edges are cut into segments; every segment is a work item
  * (item_row, item_beg); item_slot >= 0 marks a segment of a cut row and names its
