@@ -22,6 +22,7 @@ struct RowArgs {
     // layer
     int N, H, C, Cp, Dp, lph2_log;
     float neg_slope, p_drop, inv_keep;
+    uint32_t keep_thr;     // p * 2^24
     int mask_mode;
     const uint8_t *mask;
     uint64_t seed;
@@ -74,39 +75,42 @@ struct RowArgs {
 // ---------------------------------------------------------------------------------
 // Forward.  Online softmax over the row's edges: the source logit a_src[j] is
 // recomputed from the gathered row (a 4-FMA dot + head butterfly), so the only per-edge
-// HBM traffic is the col index and the feature row itself.
+// HBM traffic is the col index and the feature row itself.  Rows are gathered in
+// batches of U edges, double-buffered: batch b+1 is in flight while batch b is reduced.
+// Loads are branch-free: batch slots past the row's end re-read its last edge with
+// weight exp(-inf) = 0, idle lanes read offset 0.
 // ---------------------------------------------------------------------------------
 template <int LPH2_T, int G, int T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? 8 : (T == 2 ? 4 : 2);
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
-    float4 att[T], bia[T];
+    float4 att[T], acc[T];
     float adi[T], m[T], ssum[T];
-    float4 acc[T];
+    unsigned offb[T], hbit[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
-        bia[t] = A.bias ? ldc(A.bias + S.coff[t], S.nval[t], vec_ok)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
         adi[t] = S.nval[t] ? A.a_dst[(size_t)row * A.H + S.head[t]] : 0.f;
         m[t] = -INFINITY;
         ssum[t] = 0.f;
         acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        offb[t] = (unsigned)S.poff[t] * 4u;
+        hbit[t] = 1u << S.head[t];
     }
     for (int c = beg; c < end; c += G) {
         const int n = min(G, end - c);
-        const int cj = (lig < n) ? A.col[c + lig] : 0;
-        for (int k0 = 0; k0 < n; k0 += U) {
-            float4 v[U][T];
+        const int cl = min(lig, n - 1);
+        const int cj = A.col[c + cl];
+        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+        auto load = [&](float4(&v)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool live = k0 + u < n;
-                const int j = group_bcast<G>(cj, live ? k0 + u : 0, gbase);
+                const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
 #pragma unroll
-                for (int t = 0; t < T; ++t)
-                    v[u][t] = (live && S.nval[t]) ? ld4(A.hp + (size_t)j * A.Dp + S.poff[t])
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int t = 0; t < T; ++t) v[u][t] = ld4_row<G>(A.hp, j, A.Dp, offb[t]);
             }
+        };
+        auto reduce = [&](const float4(&v)[U][T], int k0) {
             float z[U][T];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -124,35 +128,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
                 float mn = m[t];
 #pragma unroll
                 for (int u = 0; u < U; ++u) mn = fmaxf(mn, z[u][t]);
-                const float sc = expf(m[t] - mn);
+                const float sc = exp_fast(m[t] - mn);
                 ssum[t] *= sc;
                 scale4(acc[t], sc);
                 m[t] = mn;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (k0 + u < n) {
+                const bool live = k0 + u < n;
+                const unsigned sb = (unsigned)group_bcast<G>(kb, min(k0 + u, n - 1), gbase);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        float p = expf(z[u][t] - m[t]);
-                        ssum[t] += p;
-                        p *= keep_factor(A.mask_mode, A.mask, A.seed, A.p_drop, A.inv_keep,
-                                         (long long)c + k0 + u, A.H, S.head[t]);
-                        fma4(acc[t], p, v[u][t]);
-                    }
+                for (int t = 0; t < T; ++t) {
+                    const float p = live ? exp_fast(z[u][t] - m[t]) : 0.f;
+                    ssum[t] += p;
+                    fma4(acc[t], (sb & hbit[t]) ? p * A.inv_keep : 0.f, v[u][t]);
                 }
             }
+        };
+        float4 va[U][T], vb[U][T];
+        load(va, 0);
+        for (int k0 = 0; k0 < n; k0 += 2 * U) {
+            load(vb, k0 + U);
+            reduce(va, k0);
+            load(va, k0 + 2 * U);
+            reduce(vb, k0 + U);   // unconditional: keeps the prefetch out of a branch
         }
     }
     if (slot < 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+            const float4 bia = A.bias ? ldc(A.bias + S.coff[t], S.nval[t], vec_ok)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             const float inv = ssum[t] > 0.f ? 1.0f / ssum[t] : 0.f;
             float4 o;
-            o.x = fmaf(acc[t].x, inv, bia[t].x);
-            o.y = fmaf(acc[t].y, inv, bia[t].y);
-            o.z = fmaf(acc[t].z, inv, bia[t].z);
-            o.w = fmaf(acc[t].w, inv, bia[t].w);
+            o.x = fmaf(acc[t].x, inv, bia.x);
+            o.y = fmaf(acc[t].y, inv, bia.y);
+            o.z = fmaf(acc[t].z, inv, bia.z);
+            o.w = fmaf(acc[t].w, inv, bia.w);
             stc(A.out + (size_t)row * A.H * A.C + S.coff[t], o, S.nval[t], vec_ok);
             if (A.lse && S.nval[t] && (S.poff[t] % A.Cp) == 0)
                 A.lse[(size_t)row * A.H + S.head[t]] = m[t] + logf(ssum[t]);
@@ -218,10 +230,11 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
 // ---------------------------------------------------------------------------------
 template <int LPH2_T, int G, int T>
 __global__ __launch_bounds__(256) void attn_bwd_a_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? 8 : (T == 2 ? 4 : 2);
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
     float4 att[T], g4[T];
     float adi[T], L[T], Sd[T], dad[T];
+    unsigned offb[T], hbit[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
@@ -235,47 +248,55 @@ __global__ __launch_bounds__(256) void attn_bwd_a_kernel(const RowArgs A) {
         adi[t] = S.nval[t] ? A.a_dst[(size_t)row * A.H + S.head[t]] : 0.f;
         L[t] = S.nval[t] ? A.lse_in[(size_t)row * A.H + S.head[t]] : 0.f;
         dad[t] = 0.f;
+        offb[t] = (unsigned)S.poff[t] * 4u;
+        hbit[t] = 1u << S.head[t];
         if (A.gp && S.nval[t] && beg == A.rowptr[row])
             st4(A.gp + (size_t)row * A.Dp + S.poff[t], g4[t]);
     }
     for (int c = beg; c < end; c += G) {
         const int n = min(G, end - c);
-        const int cj = (lig < n) ? A.col[c + lig] : 0;
-        const int tp = (lig < n) ? A.aux[c + lig] : 0;
-        for (int k0 = 0; k0 < n; k0 += U) {
-            float4 v[U][T];
+        const int cl = min(lig, n - 1);
+        const int cj = A.col[c + cl];
+        const int tp = A.aux[c + cl];
+        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+        auto load = [&](float4(&v)[U][T], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[u][t] = ld4_row<G>(A.hp, j, A.Dp, offb[t]);
+            }
+        };
+        auto reduce = [&](const float4(&v)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool live = k0 + u < n;
-                const int j = group_bcast<G>(cj, live ? k0 + u : 0, gbase);
+                const int kk = min(k0 + u, n - 1);
+                const int tpos = group_bcast<G>(tp, kk, gbase);
+                const unsigned sb = (unsigned)group_bcast<G>(kb, kk, gbase);
 #pragma unroll
-                for (int t = 0; t < T; ++t)
-                    v[u][t] = (live && S.nval[t]) ? ld4(A.hp + (size_t)j * A.Dp + S.poff[t])
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k0 + u < n) {
-                    const int tpos = group_bcast<G>(tp, k0 + u, gbase);
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        const float d1 = head_sum<LPH2_T>(dot4(v[u][t], att[t]), lph2);
-                        const float d2 = head_sum<LPH2_T>(dot4(v[u][t], g4[t]), lph2);
-                        const float uu = d1 + adi[t];
-                        const float zz = uu > 0.f ? uu : A.neg_slope * uu;
-                        const float alpha = expf(zz - L[t]);
-                        const float at = alpha * keep_factor(A.mask_mode, A.mask, A.seed,
-                                                             A.p_drop, A.inv_keep,
-                                                             (long long)c + k0 + u, A.H,
-                                                             S.head[t]);
-                        const float du = (at * d2 - alpha * Sd[t]) * (uu > 0.f ? 1.0f : A.neg_slope);
-                        dad[t] += du;
-                        if (S.nval[t] && (S.poff[t] % A.Cp) == 0)
-                            *reinterpret_cast<float2 *>(
-                                A.rec + ((size_t)tpos * A.H + S.head[t]) * 2) = make_float2(at, du);
-                    }
+                for (int t = 0; t < T; ++t) {
+                    const float d1 = head_sum<LPH2_T>(dot4(v[u][t], att[t]), lph2);
+                    const float d2 = head_sum<LPH2_T>(dot4(v[u][t], g4[t]), lph2);
+                    const float uu = d1 + adi[t];
+                    const float zz = uu > 0.f ? uu : A.neg_slope * uu;
+                    const float alpha = exp_fast(zz - L[t]);
+                    const float at = (sb & hbit[t]) ? alpha * A.inv_keep : 0.f;
+                    const float du = (at * d2 - alpha * Sd[t]) * (uu > 0.f ? 1.0f : A.neg_slope);
+                    dad[t] += live ? du : 0.f;
+                    if (live && S.nval[t] && (S.poff[t] % A.Cp) == 0)
+                        *reinterpret_cast<float2 *>(
+                            A.rec + ((size_t)tpos * A.H + S.head[t]) * 2) = make_float2(at, du);
                 }
             }
+        };
+        float4 va[U][T], vb[U][T];
+        load(va, 0);
+        for (int k0 = 0; k0 < n; k0 += 2 * U) {
+            load(vb, k0 + U);
+            reduce(va, k0);
+            load(va, k0 + 2 * U);
+            reduce(vb, k0 + U);   // unconditional: keeps the prefetch out of a branch
         }
     }
 #pragma unroll
@@ -328,43 +349,54 @@ __device__ __forceinline__ void bwd_b_finish(const RowArgs &A, const Slots<T> &S
 
 template <int G, int T>
 __global__ __launch_bounds__(256) void attn_bwd_b_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? 8 : (T == 2 ? 4 : 2);
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
     float4 acc[T];
     float das[T];
+    unsigned offb[T], roff[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         das[t] = 0.f;
+        offb[t] = (unsigned)S.poff[t] * 4u;
+        roff[t] = (unsigned)S.head[t] * 8u;
     }
     for (int c = beg; c < end; c += G) {
         const int n = min(G, end - c);
-        const int ci = (lig < n) ? A.col[c + lig] : 0;
-        for (int k0 = 0; k0 < n; k0 += U) {
-            float4 v[U][T];
-            float2 r[U][T];
+        const int ci = A.col[c + min(lig, n - 1)];
+        auto load = [&](float4(&v)[U][T], float2(&r)[U][T], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = min(k0 + u, n - 1);
+                const int i = group_bcast<G>(ci, kk, gbase);
+                const char *recp = reinterpret_cast<const char *>(A.rec_in) +
+                                   (size_t)(c + kk) * (size_t)A.H * 8;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    v[u][t] = ld4_row<G>(A.hp, i, A.Dp, offb[t]);
+                    r[u][t] = *reinterpret_cast<const float2 *>(recp + roff[t]);
+                }
+            }
+        };
+        auto reduce = [&](const float4(&v)[U][T], const float2(&r)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool live = k0 + u < n;
-                const int i = group_bcast<G>(ci, live ? k0 + u : 0, gbase);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    const bool ok = live && S.nval[t];
-                    v[u][t] = ok ? ld4(A.hp + (size_t)i * A.Dp + S.poff[t])
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                    r[u][t] = ok ? *reinterpret_cast<const float2 *>(
-                                       A.rec_in + ((size_t)(c + k0 + u) * A.H + S.head[t]) * 2)
-                                 : make_float2(0.f, 0.f);
+                    fma4(acc[t], live ? r[u][t].x : 0.f, v[u][t]);
+                    das[t] += live ? r[u][t].y : 0.f;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    fma4(acc[t], r[u][t].x, v[u][t]);
-                    das[t] += r[u][t].y;
-                }
-            }
+        };
+        float4 va[U][T], vb[U][T];
+        float2 ra[U][T], rb[U][T];
+        load(va, ra, 0);
+        for (int k0 = 0; k0 < n; k0 += 2 * U) {
+            load(vb, rb, k0 + U);
+            reduce(va, ra, k0);
+            load(va, ra, k0 + 2 * U);
+            reduce(vb, rb, k0 + U);
         }
     }
     if (slot < 0) {
@@ -555,6 +587,8 @@ static void fill_common(RowArgs &A, const gatmi_attn &a, const Geometry &g) {
     A.neg_slope = a.negative_slope;
     A.p_drop = a.dropout_p;
     A.inv_keep = a.dropout_p < 1.0f ? 1.0f / (1.0f - a.dropout_p) : 0.0f;
+    if (a.mask_mode == GATMI_MASK_NONE) A.inv_keep = 1.0f;
+    A.keep_thr = (uint32_t)((double)a.dropout_p * 16777216.0);
     A.mask_mode = a.mask_mode;
     A.mask = a.mask;
     A.seed = a.seed;
@@ -575,6 +609,8 @@ static int check_attn(const gatmi_graph *g, const gatmi_attn *a) {
     GATMI_REQUIRE(a->mask_mode != GATMI_MASK_BYTES || a->mask, "mask_mode BYTES needs a mask");
     GATMI_REQUIRE(a->dropout_p >= 0.f && a->dropout_p <= 1.f, "dropout_p %f outside [0,1]",
                   a->dropout_p);
+    GATMI_REQUIRE(a->mask_mode == GATMI_MASK_NONE || a->shape.heads <= 32,
+                  "attention dropout supports at most 32 heads, got %d", a->shape.heads);
     GATMI_REQUIRE(a->hp && a->a_dst && a->att_src, "null hp/a_dst/att_src");
     return GATMI_OK;
 }
@@ -587,7 +623,8 @@ namespace gatmi {
 __global__ void keep_mask_kernel(uint8_t *out, long long total, int H, uint64_t seed, float p) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x)
-        out[i] = keep_factor(GATMI_MASK_HASH, nullptr, seed, p, 1.0f, i / H, H, (int)(i % H)) != 0.f;
+        out[i] = keep_hash((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)((double)p * 16777216.0),
+                           (uint32_t)(i / H), (uint32_t)(i % H));
 }
 }  // namespace gatmi
 

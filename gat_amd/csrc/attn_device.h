@@ -93,22 +93,65 @@ __device__ __forceinline__ void stc(float *p, const float4 &v, int nval, bool ve
     }
 }
 
-// Attention-dropout keep factor of (edge e in dst-CSR order, head): 0 or 1/(1-p).
-// GATMI_MASK_HASH: a counter-based draw, the same in forward and backward.
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-    return h;
+// exp(x) through v_exp_f32 with a compensated range reduction: t = x*log2(e) rounded,
+// r = the rounding error of that product (+ the low word of log2(e)), exp(x) =
+// 2^t * (1 + r ln 2).  About 1.5 ulp for x in [-87, 0].  x is clamped at -87 (the result,
+// 1.6e-38, is 0 against a softmax denominator >= 1), which also keeps -inf from turning
+// into inf - inf in the compensation term.
+__device__ __forceinline__ float exp_fast(float x) {
+    x = fmaxf(x, -87.0f);
+    const float L2E = 1.44269502162933349609375f;      // float(log2 e)
+    const float L2E_LO = 1.925963033500011e-8f;        // log2 e - float(log2 e)
+    const float t = x * L2E;
+    float r = fmaf(x, L2E, -t);
+    r = fmaf(x, L2E_LO, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147182464599609375f, e);
 }
-__device__ __forceinline__ float keep_factor(int mode, const uint8_t *mask, uint64_t seed,
-                                             float p, float inv_keep, long long e, int heads,
-                                             int head) {
-    if (mode == 0) return 1.0f;
-    const long long idx = e * heads + head;
-    if (mode == 1) return mask[idx] ? inv_keep : 0.0f;
-    uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
-    h = mix32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32));
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);  // [0,1)
-    return u >= p ? inv_keep : 0.0f;
+
+// Attention-dropout keep decision of (edge e in dst-CSR order, head): a counter-based
+// hash of (seed, e, head), identical in forward, backward and gatmi_dropout_mask.
+__device__ __forceinline__ bool keep_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t thr,
+                                          uint32_t e, uint32_t head) {
+    uint32_t h = e * 0x9E3779B1u + seed_lo;
+    h ^= head * 0x85EBCA77u + seed_hi;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (h >> 8) >= thr;   // thr = p * 2^24
+}
+
+// Keep flags of all H (<= 32) heads of one edge, bit h = keep.  Computed lane-parallel
+// (one edge per lane) once per chunk; the per-edge loop then only tests a bit.
+__device__ __forceinline__ uint32_t keep_bits(int mode, const uint8_t *mask, uint64_t seed,
+                                              uint32_t thr, long long e, int heads) {
+    if (mode == 0) return 0xFFFFFFFFu;
+    uint32_t bits = 0;
+    if (mode == 1) {
+        const uint8_t *m = mask + e * heads;
+        for (int h = 0; h < heads; ++h) bits |= (m[h] ? 1u : 0u) << h;
+    } else {
+        for (int h = 0; h < heads; ++h)
+            bits |= (keep_hash((uint32_t)seed, (uint32_t)(seed >> 32), thr, (uint32_t)e, h) ? 1u : 0u) << h;
+    }
+    return bits;
+}
+
+// Row j of a head-padded table, this lane's 16 bytes.  G == 64: j is wave-uniform, the
+// row base lives in SGPRs as a buffer descriptor (scalar address arithmetic only) and the
+// lane offset is a loop-invariant VGPR.  G < 64: j differs per group -> plain global load.
+template <int G>
+__device__ __forceinline__ float4 ld4_row(const float *table, int j, int row_floats,
+                                          unsigned off_bytes) {
+    const char *rowp = reinterpret_cast<const char *>(table) + (size_t)j * (size_t)row_floats * 4;
+    if constexpr (G == 64) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(rowp), 0, row_floats * 4, 0x00020000);
+        const f32x4 r = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_bytes, 0, 0));
+        return make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        return *reinterpret_cast<const float4 *>(rowp + off_bytes);
+    }
 }
 
 // blockIdx -> work position such that blocks sharing an XCD (equal blockIdx % 8)
