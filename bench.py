@@ -23,11 +23,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 
 
 def kernel_bytes(n, e, h, d):
-    """Algorithmic bytes per launch of the three edge kernels (SURVEY.md 8d split)."""
+    """Algorithmic bytes per launch of the two heavy edge kernels (fp32 values, int32
+    indices).  Forward is SURVEY.md 8d's B_fwd.  The backward gathers
+    features once instead of SURVEY 8d's twice: one pass over the transposed CSR reads, per
+    edge, the grad_out row (4D), the destination's 16H-byte record, col_t and pos_t, and
+    writes d_u (4H); per node it reads h, writes d_h and d_a_src."""
     return {
         "attn_fwd": e * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
-        "attn_bwd_a": e * (4 * d + 8 * h + 4) + n * (4 * d + 12 * h),
-        "attn_bwd_b": e * (4 * d + 8 * h + 8) + n * (4 * d + 4 * h),
+        "attn_bwd_edge": e * (4 * d + 16 * h + 8 + 4 * h) + n * (8 * d + 4 * h),
     }
 
 

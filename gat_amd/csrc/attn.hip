@@ -6,6 +6,7 @@
 // (or destination) feature row exactly once, one float4 per lane.
 #include "attn_device.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace gatmi {
 
@@ -13,7 +14,7 @@ struct RowArgs {
     // CSR half being walked
     const int *rowptr;
     const int *col;
-    const int *aux;        // pass A: d2s
+    const int *aux;        // backward edge pass: pos_t (dst-CSR id of each transposed edge)
     const int *item_row;
     const int *item_beg;
     const int *item_slot;
@@ -35,17 +36,10 @@ struct RowArgs {
     float *out;
     float *lse;
     float *part_m, *part_s, *part_acc;
-    // passA
-    const float *gout;     // grad_out compact
-    const float *outc;     // forward output (with bias)
-    const float *lse_in;
-    float *gp;             // padded copy of grad_out (NULL when C % 4 == 0)
-    float *rec;            // [E', H, 2] (alpha_tilde, d_u) in transposed-CSR order
-    float *da_dst;         // [N, H]
-    float *part_dad;       // [slots, H]
-    // passB
-    const float *rec_in;
-    const float *da_dst_in;
+    // backward edge pass (transposed CSR; hp = padded grad_out there)
+    const float *hself;    // [N, Dp] projected features (row-local)
+    const float *nodeinfo; // [N, H, 4] (a_dst, lse, S, 0)
+    float *du_t;           // [E', H] d_u in transposed-CSR order
     float *dhp;            // [N, Dp]
     float *da_src;         // [N, H]
     float *part_das;       // [slots_t, H]
@@ -220,187 +214,134 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// Backward pass A (dst-CSR).  Per edge e = (j -> i):
-//   alpha   = exp(leaky(a_src[j] + a_dst[i]) - lse[i])         (a_src[j] recomputed)
-//   d_at    = <grad_out[i,h,:], h[j,h,:]>
-//   d_u     = (alpha_tilde * d_at - alpha * S_i) * leaky'(u),  S_i = <grad_out[i], out[i] - bias>
-// S_i equals sum_e alpha_e * d_alpha_e because out[i] - bias = sum_e alpha_tilde_e h[j].
-// Writes the record (alpha_tilde, d_u) at the edge's transposed-CSR position, and
-// d a_dst[i] = sum_e d_u.
+// Backward.  One heavy pass over the TRANSPOSED CSR (source rows) does all the per-edge
+// work, so the projected features are not gathered a second time:
+//
+//   prep      per node i:   S_i = <grad_out[i], out[i] - bias>  (= sum_e alpha_e d_alpha_e,
+//             because out[i] - bias = sum_e alpha~_e h[j]); packs (a_dst, lse, S) per head
+//             into a 16-byte record; pads grad_out when C % 4 != 0.
+//   edge      per source j (h[j] and a_src[j] row-local), per out-edge e = (j -> i):
+//               gather grad_out[i] (one float4 per lane) and node record i
+//               alpha  = exp(leaky(a_src[j] + a_dst[i]) - lse[i])
+//               d_at   = <grad_out[i,h,:], h[j,h,:]>
+//               d_u    = (alpha~ d_at - alpha S_i) * leaky'(u)        -> du_t[e] (src order)
+//               d_h[j] += alpha~ grad_out[i];   d_a_src[j] += d_u
+//             then d_h[j] += d_a_src[j] att_src
+//   dst       per destination i: d_a_dst[i] = sum over in-edges of du_t (light: 4H bytes
+//             per edge through d2s)
+//   colsum    d_h[i] += d_a_dst[i] att_dst (row-local fix-up) fused with the parameter
+//             column sums.
 // ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bwd_prep_kernel(
+    const float *gout, const float *outc, const float *bias, const float *a_dst, const float *lse,
+    long long total_groups, int H, int C, int Cp, float4 *nodeinfo, float *gp) {
+    __shared__ float part[256];
+    const int lph = Cp >> 2;
+    const int R = 256 / lph;
+    const long long g0 = (long long)blockIdx.x * R;
+    const int t = threadIdx.x, gl = t / lph, sub = t % lph;
+    const long long grp = g0 + gl;  // = node * H + head
+    float p = 0.f;
+    if (gl < R && grp < total_groups) {
+        const int head = (int)(grp % H);
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = sub * 4 + k;
+            if (c < C) {
+                const float g = gout[(size_t)grp * C + c];
+                const float o = outc[(size_t)grp * C + c] - (bias ? bias[head * C + c] : 0.f);
+                gv[k] = g;
+                p = fmaf(g, o, p);
+            }
+        }
+        if (gp) st4(gp + (size_t)grp * Cp + sub * 4, make_float4(gv[0], gv[1], gv[2], gv[3]));
+    }
+    part[t] = p;
+    __syncthreads();
+    if (t < R && g0 + t < total_groups) {
+        float sd = 0.f;
+        for (int q = 0; q < lph; ++q) sd += part[t * lph + q];
+        nodeinfo[g0 + t] = make_float4(a_dst[g0 + t], lse[g0 + t], sd, 0.f);
+    }
+}
+
 template <int LPH2_T, int G, int T>
-__global__ __launch_bounds__(256) void attn_bwd_a_kernel(const RowArgs A) {
+__global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
     constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
-    float4 att[T], g4[T];
-    float adi[T], L[T], Sd[T], dad[T];
-    unsigned offb[T], hbit[T];
+    float4 att[T], hj[T], acc[T];
+    float asj[T], das[T];
+    unsigned offb[T], hbit[T], noff[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
-        g4[t] = ldc(A.gout + (size_t)row * A.H * A.C + S.coff[t], S.nval[t], vec_ok);
-        float4 o = ldc(A.outc + (size_t)row * A.H * A.C + S.coff[t], S.nval[t], vec_ok);
-        if (A.bias) {
-            const float4 b = ldc(A.bias + S.coff[t], S.nval[t], vec_ok);
-            o.x -= b.x; o.y -= b.y; o.z -= b.z; o.w -= b.w;
-        }
-        Sd[t] = head_sum<LPH2_T>(dot4(g4[t], o), lph2);
-        adi[t] = S.nval[t] ? A.a_dst[(size_t)row * A.H + S.head[t]] : 0.f;
-        L[t] = S.nval[t] ? A.lse_in[(size_t)row * A.H + S.head[t]] : 0.f;
-        dad[t] = 0.f;
+        hj[t] = S.nval[t] ? ld4(A.hself + (size_t)row * A.Dp + S.poff[t])
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        asj[t] = head_sum<LPH2_T>(dot4(hj[t], att[t]), lph2);
+        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        das[t] = 0.f;
         offb[t] = (unsigned)S.poff[t] * 4u;
+        noff[t] = (unsigned)S.head[t] * 16u;
         hbit[t] = 1u << S.head[t];
-        if (A.gp && S.nval[t] && beg == A.rowptr[row])
-            st4(A.gp + (size_t)row * A.Dp + S.poff[t], g4[t]);
     }
     for (int c = beg; c < end; c += G) {
         const int n = min(G, end - c);
         const int cl = min(lig, n - 1);
-        const int cj = A.col[c + cl];
-        const int tp = A.aux[c + cl];
-        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
-        auto load = [&](float4(&v)[U][T], int k0) {
+        const int ci = A.col[c + cl];
+        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+                                      (long long)A.aux[c + cl], A.H);
+        auto load = [&](float4(&v)[U][T], float4(&q)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
-#pragma unroll
-                for (int t = 0; t < T; ++t) v[u][t] = ld4_row<G>(A.hp, j, A.Dp, offb[t]);
-            }
-        };
-        auto reduce = [&](const float4(&v)[U][T], int k0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = k0 + u < n;
-                const int kk = min(k0 + u, n - 1);
-                const int tpos = group_bcast<G>(tp, kk, gbase);
-                const unsigned sb = (unsigned)group_bcast<G>(kb, kk, gbase);
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const float d1 = head_sum<LPH2_T>(dot4(v[u][t], att[t]), lph2);
-                    const float d2 = head_sum<LPH2_T>(dot4(v[u][t], g4[t]), lph2);
-                    const float uu = d1 + adi[t];
-                    const float zz = uu > 0.f ? uu : A.neg_slope * uu;
-                    const float alpha = exp_fast(zz - L[t]);
-                    const float at = (sb & hbit[t]) ? alpha * A.inv_keep : 0.f;
-                    const float du = (at * d2 - alpha * Sd[t]) * (uu > 0.f ? 1.0f : A.neg_slope);
-                    dad[t] += live ? du : 0.f;
-                    if (live && S.nval[t] && (S.poff[t] % A.Cp) == 0)
-                        *reinterpret_cast<float2 *>(
-                            A.rec + ((size_t)tpos * A.H + S.head[t]) * 2) = make_float2(at, du);
-                }
-            }
-        };
-        float4 va[U][T], vb[U][T];
-        load(va, 0);
-        for (int k0 = 0; k0 < n; k0 += 2 * U) {
-            load(vb, k0 + U);
-            reduce(va, k0);
-            load(va, k0 + 2 * U);
-            reduce(vb, k0 + U);   // unconditional: keeps the prefetch out of a branch
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (S.nval[t] && (S.poff[t] % A.Cp) == 0) {
-            if (slot < 0)
-                A.da_dst[(size_t)row * A.H + S.head[t]] = dad[t];
-            else
-                A.part_dad[(size_t)slot * A.H + S.head[t]] = dad[t];
-        }
-    }
-    GATMI_ITEM_LOOP_END
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_a_merge_kernel(
-    const int *split_row, const int *split_slot, int n_split, int H, const float *part_dad,
-    float *da_dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_split * H) return;
-    const int w = idx / H, head = idx % H;
-    float acc = 0.f;
-    for (int s = split_slot[w]; s < split_slot[w + 1]; ++s) acc += part_dad[(size_t)s * H + head];
-    da_dst[(size_t)split_row[w] * H + head] = acc;
-}
-
-// ---------------------------------------------------------------------------------
-// Backward pass B (transposed CSR).  For source j:
-//   d_h[j] = sum_{e=(j->i)} alpha_tilde_e * grad_out[i]  +  d_a_src[j] att_src + d_a_dst[j] att_dst
-//   d_a_src[j] = sum_e d_u_e
-// Records are read sequentially (pass A wrote them in this order); grad_out rows are
-// gathered from the head-padded copy.
-// ---------------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ void bwd_b_finish(const RowArgs &A, const Slots<T> &S, bool vec_ok,
-                                             int row, float4 *acc, const float *das) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (S.nval[t]) {
-            const float4 as4 = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
-            const float4 ad4 = ldc(A.att_dst + S.coff[t], S.nval[t], vec_ok);
-            const float dd = A.da_dst_in[(size_t)row * A.H + S.head[t]];
-            float4 o = acc[t];
-            fma4(o, das[t], as4);
-            fma4(o, dd, ad4);
-            st4(A.dhp + (size_t)row * A.Dp + S.poff[t], o);
-            if ((S.poff[t] % A.Cp) == 0) A.da_src[(size_t)row * A.H + S.head[t]] = das[t];
-        }
-    }
-}
-
-template <int G, int T>
-__global__ __launch_bounds__(256) void attn_bwd_b_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
-    GATMI_ITEM_LOOP_BEGIN
-    float4 acc[T];
-    float das[T];
-    unsigned offb[T], roff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        das[t] = 0.f;
-        offb[t] = (unsigned)S.poff[t] * 4u;
-        roff[t] = (unsigned)S.head[t] * 8u;
-    }
-    for (int c = beg; c < end; c += G) {
-        const int n = min(G, end - c);
-        const int ci = A.col[c + min(lig, n - 1)];
-        auto load = [&](float4(&v)[U][T], float2(&r)[U][T], int k0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int kk = min(k0 + u, n - 1);
-                const int i = group_bcast<G>(ci, kk, gbase);
-                const char *recp = reinterpret_cast<const char *>(A.rec_in) +
-                                   (size_t)(c + kk) * (size_t)A.H * 8;
+                const int i = group_bcast<G>(ci, min(k0 + u, n - 1), gbase);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     v[u][t] = ld4_row<G>(A.hp, i, A.Dp, offb[t]);
-                    r[u][t] = *reinterpret_cast<const float2 *>(recp + roff[t]);
+                    q[u][t] = ld4_row<G>(A.nodeinfo, i, A.H * 4, noff[t]);
                 }
             }
         };
-        auto reduce = [&](const float4(&v)[U][T], const float2(&r)[U][T], int k0) {
+        auto reduce = [&](const float4(&v)[U][T], const float4(&q)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool live = k0 + u < n;
+                const int kk = min(k0 + u, n - 1);
+                const unsigned sb = (unsigned)group_bcast<G>(kb, kk, gbase);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    fma4(acc[t], live ? r[u][t].x : 0.f, v[u][t]);
-                    das[t] += live ? r[u][t].y : 0.f;
+                    const float d2 = head_sum<LPH2_T>(dot4(v[u][t], hj[t]), lph2);
+                    const float uu = asj[t] + q[u][t].x;
+                    const float zz = uu > 0.f ? uu : A.neg_slope * uu;
+                    const float alpha = live ? exp_fast(zz - q[u][t].y) : 0.f;
+                    const float at = (sb & hbit[t]) ? alpha * A.inv_keep : 0.f;
+                    const float du = (at * d2 - alpha * q[u][t].z) * (uu > 0.f ? 1.0f : A.neg_slope);
+                    fma4(acc[t], at, v[u][t]);
+                    das[t] += du;
+                    if (live && S.nval[t] && (S.poff[t] % A.Cp) == 0)
+                        A.du_t[(size_t)(c + kk) * A.H + S.head[t]] = du;
                 }
             }
         };
-        float4 va[U][T], vb[U][T];
-        float2 ra[U][T], rb[U][T];
-        load(va, ra, 0);
+        float4 va[U][T], vb[U][T], qa[U][T], qb[U][T];
+        load(va, qa, 0);
         for (int k0 = 0; k0 < n; k0 += 2 * U) {
-            load(vb, rb, k0 + U);
-            reduce(va, ra, k0);
-            load(va, ra, k0 + 2 * U);
-            reduce(vb, rb, k0 + U);
+            load(vb, qb, k0 + U);
+            reduce(va, qa, k0);
+            load(va, qa, k0 + 2 * U);
+            reduce(vb, qb, k0 + U);
         }
     }
     if (slot < 0) {
-        bwd_b_finish<T>(A, S, vec_ok, row, acc, das);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (S.nval[t]) {
+                float4 o = acc[t];
+                fma4(o, das[t], att[t]);
+                st4(A.dhp + (size_t)row * A.Dp + S.poff[t], o);
+                if ((S.poff[t] % A.Cp) == 0) A.da_src[(size_t)row * A.H + S.head[t]] = das[t];
+            }
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -413,10 +354,11 @@ __global__ __launch_bounds__(256) void attn_bwd_b_kernel(const RowArgs A) {
     GATMI_ITEM_LOOP_END
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_b_merge_kernel(
+// Merge of the partial (d_h, d_a_src) of source rows cut into segments; segment order fixed.
+__global__ __launch_bounds__(256) void attn_bwd_edge_merge_kernel(
     const int *split_row, const int *split_slot, int n_split, int H, int C, int Cp, int Dp,
-    const float *part_dh, const float *part_das, const float *att_src, const float *att_dst,
-    const float *da_dst, float *dhp, float *da_src) {
+    const float *part_dh, const float *part_das, const float *att_src, float *dhp,
+    float *da_src) {
     const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (w >= n_split) return;
     const int lane = threadIdx.x & 63;
@@ -431,18 +373,50 @@ __global__ __launch_bounds__(256) void attn_bwd_b_merge_kernel(
             const float4 p = ld4(part_dh + (size_t)s * Dp + head * Cp + sub * 4);
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
-        const float dd = da_dst[(size_t)row * H + head];
         float o[4] = {acc.x, acc.y, acc.z, acc.w};
         for (int k = 0; k < 4; ++k) {
             const int c = sub * 4 + k;
-            if (c < C) {
-                o[k] = fmaf(das, att_src[head * C + c], o[k]);
-                o[k] = fmaf(dd, att_dst[head * C + c], o[k]);
-            }
+            if (c < C) o[k] = fmaf(das, att_src[head * C + c], o[k]);
         }
         st4(dhp + (size_t)row * Dp + head * Cp + sub * 4, make_float4(o[0], o[1], o[2], o[3]));
         if (sub == 0) da_src[(size_t)row * H + head] = das;
     }
+}
+
+// d_a_dst[i,h] = sum of du_t over the in-edges of i, in dst-CSR order.  One wave per work
+// item; lane = (edge slot, head) with the head count padded to a power of two.
+__global__ __launch_bounds__(256) void attn_bwd_dst_kernel(
+    const int *rowptr, const int *d2s, const int *item_row, const int *item_beg,
+    const int *item_slot, int n_items, int seg_len, int H, int hp2_log, const float *du_t,
+    float *da_dst, float *part_dad) {
+    const int lane = threadIdx.x & 63;
+    const int hp2 = 1 << hp2_log;
+    const int h = lane & (hp2 - 1), eo = lane >> hp2_log, epw = 64 >> hp2_log;
+    const int waves = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + (threadIdx.x >> 6); it < n_items; it += waves) {
+        const int row = item_row[it], beg = item_beg[it], slot = item_slot[it];
+        const int end = min(rowptr[row + 1], beg + seg_len);
+        float s = 0.f;
+        for (int e = beg + eo; e < end; e += epw)
+            if (h < H) s += du_t[(size_t)d2s[e] * H + h];
+        // sum over the lanes that share h: strides hp2, 2*hp2, ... 32 -- a fixed tree
+        for (int o = hp2; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (eo == 0 && h < H) {
+            if (slot < 0) da_dst[(size_t)row * H + h] = s;
+            else part_dad[(size_t)slot * H + h] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dst_merge_kernel(
+    const int *split_row, const int *split_slot, int n_split, int H, const float *part_dad,
+    float *da_dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_split * H) return;
+    const int w = idx / H, head = idx % H;
+    float acc = 0.f;
+    for (int s = split_slot[w]; s < split_slot[w + 1]; ++s) acc += part_dad[(size_t)s * H + head];
+    da_dst[(size_t)split_row[w] * H + head] = acc;
 }
 
 // ---------------------------------------------------------------------------------
@@ -454,8 +428,9 @@ __global__ __launch_bounds__(256) void attn_bwd_b_merge_kernel(
 constexpr int kColsumBlocks = 1024;
 
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(
-    const float *hp, const float *gp, const float *da_src, const float *da_dst, int N, int H,
-    int Cp, int Dp, float *partial /* [blocks, 3, Dp] */) {
+    const float *hp, const float *gp, const float *da_src, const float *da_dst,
+    const float *att_dst, float *dhp, int N, int H, int C, int Cp, int Dp,
+    float *partial /* [blocks, 3, Dp] */) {
     __shared__ float4 red[3][256];
     const int nslot = Dp >> 2;  // float4 slots per row, <= 256
     const int rows_per_pass = 256 / nslot;
@@ -463,6 +438,16 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
     const int rsub = threadIdx.x / nslot;
     const int head = (slot * 4) / Cp;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, g = a;
+    float4 ad4 = a;  // att_dst of this slot (0 in the padding)
+    {
+        const int c0 = slot * 4 - head * Cp;
+        if (slot < nslot) {
+            if (c0 + 0 < C) ad4.x = att_dst[head * C + c0 + 0];
+            if (c0 + 1 < C) ad4.y = att_dst[head * C + c0 + 1];
+            if (c0 + 2 < C) ad4.z = att_dst[head * C + c0 + 2];
+            if (c0 + 3 < C) ad4.w = att_dst[head * C + c0 + 3];
+        }
+    }
     if (rsub < rows_per_pass) {
         const long long rows_per_block = ((long long)N + gridDim.x - 1) / gridDim.x;
         const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -470,8 +455,12 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
         for (long long r = r0 + rsub; r < r1; r += rows_per_pass) {
             const float4 hv = ld4(hp + r * Dp + slot * 4);
             const float4 gv = ld4(gp + r * Dp + slot * 4);
+            const float dd = da_dst[r * H + head];
             fma4(a, da_src[r * H + head], hv);
-            fma4(b, da_dst[r * H + head], hv);
+            fma4(b, dd, hv);
+            float4 dh = ld4(dhp + r * Dp + slot * 4);  // d_h[r] += d_a_dst[r] att_dst
+            fma4(dh, dd, ad4);
+            st4(dhp + r * Dp + slot * 4, dh);
             g.x += gv.x; g.y += gv.y; g.z += gv.z; g.w += gv.w;
         }
     }
@@ -536,16 +525,14 @@ static int make_geometry(const gatmi_shape &s, Geometry *g) {
     return GATMI_OK;
 }
 
-enum Kind { FWD, BWD_A, BWD_B };
+enum Kind { FWD, BWD_EDGE };
 
 template <int LPH2_T, int G, int T>
 static void launch_kind(Kind k, const RowArgs &A, int grid, hipStream_t st) {
     if (k == FWD)
         hipLaunchKernelGGL((attn_fwd_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
-    else if (k == BWD_A)
-        hipLaunchKernelGGL((attn_bwd_a_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
     else
-        hipLaunchKernelGGL((attn_bwd_b_kernel<G, T>), dim3(grid), dim3(256), 0, st, A);
+        hipLaunchKernelGGL((attn_bwd_edge_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
 }
 
 static int launch_rows(Kind k, const Geometry &g, const RowArgs &A, hipStream_t st) {
@@ -692,14 +679,15 @@ extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *
 
 namespace {
 struct BwdWs {
-    float *rec, *gp, *da_dst, *da_src, *part_dad, *part_das, *part_dh, *colsum;
+    float *nodeinfo, *du_t, *gp, *da_dst, *da_src, *part_dad, *part_das, *part_dh, *colsum;
     size_t bytes;
 };
 BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws) {
     Carver cv(ws);
     BwdWs w;
     const size_t N = (size_t)s->num_nodes, H = (size_t)s->heads;
-    w.rec = cv.take<float>((size_t)g->num_edges * H * 2);
+    w.nodeinfo = cv.take<float>(N * H * 4);
+    w.du_t = cv.take<float>((size_t)g->num_edges * H);
     w.gp = (s->channels & 3) ? cv.take<float>(N * geo.Dp) : nullptr;
     w.da_dst = cv.take<float>(N * H);
     w.da_src = cv.take<float>(N * H);
@@ -733,79 +721,79 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const BwdWs w = carve_bwd(g, &a->shape, geo, ws);
+    const int N = a->shape.num_nodes, H = a->shape.heads, C = a->shape.channels;
+    if (N == 0) return GATMI_OK;
 
-    RowArgs A;
-    fill_common(A, *a, geo);
-    A.rowptr = g->rowptr;
-    A.col = g->col;
-    A.aux = g->d2s;
-    A.item_row = g->plan.item_row;
-    A.item_beg = g->plan.item_beg;
-    A.item_slot = g->plan.item_slot;
-    A.n_items = g->plan.n_items;
-    A.seg_len = g->seg_len;
-    A.gout = grad_out;
-    A.outc = out;
-    A.lse_in = lse;
-    A.gp = w.gp;
-    A.rec = w.rec;
-    A.da_dst = w.da_dst;
-    A.part_dad = w.part_dad;
     {
-        ProfScope ps("attn_bwd_a", st);
-        if (int e = launch_rows(BWD_A, geo, A, st)) return e;
-    }
-    if (g->plan.n_split_rows > 0) {
-        ProfScope ps("attn_bwd_a_merge", st);
-        const int tot = g->plan.n_split_rows * A.H;
-        hipLaunchKernelGGL(attn_bwd_a_merge_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
-                           g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H,
-                           w.part_dad, w.da_dst);
+        ProfScope ps("attn_bwd_prep", st);
+        const long long groups = (long long)N * H;
+        const int R = 256 / (geo.Cp / 4);
+        hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)((groups + R - 1) / R)), dim3(256), 0, st,
+                           grad_out, out, a->bias, a->a_dst, lse, groups, H, C, geo.Cp,
+                           reinterpret_cast<float4 *>(w.nodeinfo), w.gp);
         GATMI_HIP(hipGetLastError());
     }
-
     const float *gpad = w.gp ? w.gp : grad_out;
+
     RowArgs B;
     fill_common(B, *a, geo);
     B.hp = gpad;
+    B.hself = a->hp;
+    B.nodeinfo = w.nodeinfo;
     B.rowptr = g->rowptr_t;
     B.col = g->col_t;
+    B.aux = g->pos_t;
     B.item_row = g->plan_t.item_row;
     B.item_beg = g->plan_t.item_beg;
     B.item_slot = g->plan_t.item_slot;
     B.n_items = g->plan_t.n_items;
     B.seg_len = g->seg_len;
-    B.rec_in = w.rec;
-    B.da_dst_in = w.da_dst;
+    B.du_t = w.du_t;
     B.dhp = d_hp;
     B.da_src = w.da_src;
     B.part_das = w.part_das;
     B.part_dh = w.part_dh;
     {
-        ProfScope ps("attn_bwd_b", st);
-        if (int e = launch_rows(BWD_B, geo, B, st)) return e;
+        ProfScope ps("attn_bwd_edge", st);
+        if (int e = launch_rows(BWD_EDGE, geo, B, st)) return e;
     }
     if (g->plan_t.n_split_rows > 0) {
-        ProfScope ps("attn_bwd_b_merge", st);
+        ProfScope ps("attn_bwd_edge_merge", st);
         const int blocks = (g->plan_t.n_split_rows + 3) / 4;
-        hipLaunchKernelGGL(attn_bwd_b_merge_kernel, dim3(blocks), dim3(256), 0, st,
-                           g->plan_t.split_row, g->plan_t.split_slot, g->plan_t.n_split_rows, A.H,
-                           A.C, A.Cp, A.Dp, w.part_dh, w.part_das, a->att_src, a->att_dst,
-                           w.da_dst, d_hp, w.da_src);
+        hipLaunchKernelGGL(attn_bwd_edge_merge_kernel, dim3(blocks), dim3(256), 0, st,
+                           g->plan_t.split_row, g->plan_t.split_slot, g->plan_t.n_split_rows, H, C,
+                           geo.Cp, geo.Dp, w.part_dh, w.part_das, a->att_src, d_hp, w.da_src);
         GATMI_HIP(hipGetLastError());
     }
-
-    if (d_att_src || d_att_dst || d_bias) {
+    {
+        ProfScope ps("attn_bwd_dst", st);
+        const int hp2_log = ilog2(next_pow2(H));
+        GATMI_REQUIRE(hp2_log <= 6, "more than 64 heads");
+        const int grid = item_grid(g->plan.n_items, 4);
+        hipLaunchKernelGGL(attn_bwd_dst_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->d2s,
+                           g->plan.item_row, g->plan.item_beg, g->plan.item_slot, g->plan.n_items,
+                           g->seg_len, H, hp2_log, w.du_t, w.da_dst, w.part_dad);
+        GATMI_HIP(hipGetLastError());
+        if (g->plan.n_split_rows > 0) {
+            const int tot = g->plan.n_split_rows * H;
+            hipLaunchKernelGGL(attn_bwd_dst_merge_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
+                               g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, H,
+                               w.part_dad, w.da_dst);
+            GATMI_HIP(hipGetLastError());
+        }
+    }
+    {
         ProfScope ps("param_colsum", st);
-        const int N = a->shape.num_nodes;
-        const int blocks = N < kColsumBlocks ? (N > 0 ? N : 1) : kColsumBlocks;
+        const int blocks = N < kColsumBlocks ? N : kColsumBlocks;
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, gpad,
-                           w.da_src, w.da_dst, N, A.H, A.Cp, A.Dp, w.colsum);
+                           w.da_src, w.da_dst, a->att_dst, d_hp, N, H, C, geo.Cp, geo.Dp, w.colsum);
         GATMI_HIP(hipGetLastError());
-        const int tot = 3 * A.H * A.C;
-        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
-                           w.colsum, blocks, A.H, A.C, A.Cp, A.Dp, d_att_src, d_att_dst, d_bias);
-        GATMI_HIP(hipGetLastError());
+        if (d_att_src || d_att_dst || d_bias) {
+            const int tot = 3 * H * C;
+            hipLaunchKernelGGL(colsum_stage2_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
+                               w.colsum, blocks, H, C, geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
+            GATMI_HIP(hipGetLastError());
+        }
     }
     return GATMI_OK;
 }
