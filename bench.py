@@ -84,6 +84,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
                              "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    local = local % max(torch.cuda.device_count(), 1)   # >1 rank per GPU only in gloo rehearsals
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -92,7 +93,11 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GAT_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         from gat_amd.dist import bench_partitioned
         return bench_partitioned(args, rank, world, dev)
 

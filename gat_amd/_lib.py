@@ -24,8 +24,9 @@ class Plan(C.Structure):
 
 
 class Graph(C.Structure):
-    _fields_ = [("num_nodes", C.c_int32), ("num_edges", C.c_int32), ("seg_len", C.c_int32),
-                ("_pad", C.c_int32), ("rowptr", C.c_void_p), ("col", C.c_void_p),
+    _fields_ = [("num_src", C.c_int32), ("num_dst", C.c_int32), ("num_edges", C.c_int32),
+                ("seg_len", C.c_int32), ("dst_offset", C.c_int32), ("_pad", C.c_int32),
+                ("rowptr", C.c_void_p), ("col", C.c_void_p),
                 ("perm", C.c_void_p), ("rowptr_t", C.c_void_p), ("col_t", C.c_void_p),
                 ("pos_t", C.c_void_p), ("d2s", C.c_void_p), ("plan", Plan), ("plan_t", Plan)]
 
@@ -53,9 +54,9 @@ SYMBOLS = {
     "gatmi_version": (C.c_int, []),
     "gatmi_prof_enable": (C.c_int, [C.c_int]),
     "gatmi_prof_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.c_int]),
-    "gatmi_graph_sizes_query": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int,
+    "gatmi_graph_sizes_query": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                           C.POINTER(GraphSizes)]),
-    "gatmi_graph_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+    "gatmi_graph_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                     C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_project_workspace_bytes": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_project_fwd": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -70,7 +71,9 @@ SYMBOLS = {
     "gatmi_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_attn_bwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_add_dst_term": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
 }
 
 _lib = None

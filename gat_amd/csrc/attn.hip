@@ -429,8 +429,8 @@ constexpr int kColsumBlocks = 1024;
 
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(
     const float *hp, const float *gp, const float *da_src, const float *da_dst,
-    const float *att_dst, float *dhp, int N, int H, int C, int Cp, int Dp,
-    float *partial /* [blocks, 3, Dp] */) {
+    const float *att_dst, float *dhp /* NULL: no fix-up */, int n_src, int n_dst, int dst_off,
+    int H, int C, int Cp, int Dp, float *partial /* [blocks, 3, Dp] */) {
     __shared__ float4 red[3][256];
     const int nslot = Dp >> 2;  // float4 slots per row, <= 256
     const int rows_per_pass = 256 / nslot;
@@ -441,27 +441,29 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
     float4 ad4 = a;  // att_dst of this slot (0 in the padding)
     {
         const int c0 = slot * 4 - head * Cp;
-        if (slot < nslot) {
-            if (c0 + 0 < C) ad4.x = att_dst[head * C + c0 + 0];
-            if (c0 + 1 < C) ad4.y = att_dst[head * C + c0 + 1];
-            if (c0 + 2 < C) ad4.z = att_dst[head * C + c0 + 2];
-            if (c0 + 3 < C) ad4.w = att_dst[head * C + c0 + 3];
-        }
+        if (c0 + 0 < C) ad4.x = att_dst[head * C + c0 + 0];
+        if (c0 + 1 < C) ad4.y = att_dst[head * C + c0 + 1];
+        if (c0 + 2 < C) ad4.z = att_dst[head * C + c0 + 2];
+        if (c0 + 3 < C) ad4.w = att_dst[head * C + c0 + 3];
     }
     if (rsub < rows_per_pass) {
-        const long long rows_per_block = ((long long)N + gridDim.x - 1) / gridDim.x;
+        const long long n_max = n_src > n_dst ? n_src : n_dst;
+        const long long rows_per_block = (n_max + gridDim.x - 1) / gridDim.x;
         const long long r0 = (long long)blockIdx.x * rows_per_block;
-        const long long r1 = min((long long)N, r0 + rows_per_block);
+        const long long r1 = min(n_max, r0 + rows_per_block);
         for (long long r = r0 + rsub; r < r1; r += rows_per_pass) {
-            const float4 hv = ld4(hp + r * Dp + slot * 4);
-            const float4 gv = ld4(gp + r * Dp + slot * 4);
-            const float dd = da_dst[r * H + head];
-            fma4(a, da_src[r * H + head], hv);
-            fma4(b, dd, hv);
-            float4 dh = ld4(dhp + r * Dp + slot * 4);  // d_h[r] += d_a_dst[r] att_dst
-            fma4(dh, dd, ad4);
-            st4(dhp + r * Dp + slot * 4, dh);
-            g.x += gv.x; g.y += gv.y; g.z += gv.z; g.w += gv.w;
+            if (r < n_src) fma4(a, da_src[r * H + head], ld4(hp + r * Dp + slot * 4));
+            if (r < n_dst) {
+                const float dd = da_dst[r * H + head];
+                fma4(b, dd, ld4(hp + (r + dst_off) * Dp + slot * 4));
+                const float4 gv = ld4(gp + r * Dp + slot * 4);
+                g.x += gv.x; g.y += gv.y; g.z += gv.z; g.w += gv.w;
+                if (dhp) {  // d_h[r] += d_a_dst[r] att_dst
+                    float4 dh = ld4(dhp + (r + dst_off) * Dp + slot * 4);
+                    fma4(dh, dd, ad4);
+                    st4(dhp + (r + dst_off) * Dp + slot * 4, dh);
+                }
+            }
         }
     }
     red[0][threadIdx.x] = a;
@@ -477,6 +479,28 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
             }
             st4(partial + ((size_t)blockIdx.x * 3 + k) * Dp + slot * 4, s);
         }
+    }
+}
+
+// d_h[i] += d_a_dst[i] att_dst for a block of rows (the partitioned layer applies it
+// after the reduce-scatter of d_h).
+__global__ __launch_bounds__(256) void add_dst_term_kernel(float *dh, const float *da_dst,
+                                                           const float *att_dst, long long n, int H,
+                                                           int C, int Cp) {
+    const int lph = Cp >> 2;
+    const long long total = n * H * lph;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+        const int sub = (int)(i % lph);
+        const long long grp = i / lph;  // node * H + head
+        const int head = (int)(grp % H);
+        const float dd = da_dst[grp];
+        float4 v = ld4(dh + grp * Cp + sub * 4);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < 4; ++k) {
+            const int c = sub * 4 + k;
+            if (c < C) o[k] = fmaf(dd, att_dst[head * C + c], o[k]);
+        }
+        st4(dh + grp * Cp + sub * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -588,8 +612,12 @@ static void fill_common(RowArgs &A, const gatmi_attn &a, const Geometry &g) {
 
 static int check_attn(const gatmi_graph *g, const gatmi_attn *a) {
     GATMI_REQUIRE(g && a, "null graph/attn descriptor");
-    GATMI_REQUIRE(g->num_nodes == a->shape.num_nodes, "graph has %d nodes, layer %d",
-                  g->num_nodes, a->shape.num_nodes);
+    GATMI_REQUIRE(g->num_dst == a->shape.num_nodes, "graph has %d destination rows, layer %d",
+                  g->num_dst, a->shape.num_nodes);
+    GATMI_REQUIRE(g->num_src >= g->num_dst && g->dst_offset >= 0 &&
+                      g->dst_offset + g->num_dst <= g->num_src,
+                  "destination rows [%d, %d) outside the %d source rows", g->dst_offset,
+                  g->dst_offset + g->num_dst, g->num_src);
     GATMI_REQUIRE(g->seg_len >= 64 && g->seg_len % 64 == 0, "seg_len %d must be a multiple of 64",
                   g->seg_len);
     GATMI_REQUIRE(a->mask_mode >= 0 && a->mask_mode <= 2, "bad mask_mode %d", a->mask_mode);
@@ -685,12 +713,12 @@ struct BwdWs {
 BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws) {
     Carver cv(ws);
     BwdWs w;
-    const size_t N = (size_t)s->num_nodes, H = (size_t)s->heads;
+    const size_t N = (size_t)g->num_dst, NS = (size_t)g->num_src, H = (size_t)s->heads;
     w.nodeinfo = cv.take<float>(N * H * 4);
     w.du_t = cv.take<float>((size_t)g->num_edges * H);
     w.gp = (s->channels & 3) ? cv.take<float>(N * geo.Dp) : nullptr;
     w.da_dst = cv.take<float>(N * H);
-    w.da_src = cv.take<float>(N * H);
+    w.da_src = cv.take<float>(NS * H);
     w.part_dad = cv.take<float>((size_t)g->plan.n_slots * H);
     w.part_das = cv.take<float>((size_t)g->plan_t.n_slots * H);
     w.part_dh = cv.take<float>((size_t)g->plan_t.n_slots * geo.Dp);
@@ -708,8 +736,8 @@ extern "C" size_t gatmi_attn_bwd_workspace_bytes(const gatmi_graph *g, const gat
 
 extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
                               const float *lse, const float *grad_out, float *d_hp,
-                              float *d_att_src, float *d_att_dst, float *d_bias, void *ws,
-                              size_t ws_bytes, void *stream) {
+                              float *d_att_src, float *d_att_dst, float *d_bias,
+                              float *d_a_dst_out, void *ws, size_t ws_bytes, void *stream) {
     if (int e = check_attn(g, a)) return e;
     Geometry geo;
     if (int e = make_geometry(a->shape, &geo)) return e;
@@ -721,8 +749,10 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const BwdWs w = carve_bwd(g, &a->shape, geo, ws);
-    const int N = a->shape.num_nodes, H = a->shape.heads, C = a->shape.channels;
-    if (N == 0) return GATMI_OK;
+    const int N = g->num_dst, NS = g->num_src, H = a->shape.heads, C = a->shape.channels;
+    GATMI_REQUIRE(d_a_dst_out || N == NS,
+                  "a destination partition must take d_a_dst (the d_h fix-up follows its reduce-scatter)");
+    if (NS == 0) return GATMI_OK;
 
     {
         ProfScope ps("attn_bwd_prep", st);
@@ -784,9 +814,10 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     }
     {
         ProfScope ps("param_colsum", st);
-        const int blocks = N < kColsumBlocks ? N : kColsumBlocks;
+        const int blocks = NS < kColsumBlocks ? NS : kColsumBlocks;
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, gpad,
-                           w.da_src, w.da_dst, a->att_dst, d_hp, N, H, C, geo.Cp, geo.Dp, w.colsum);
+                           w.da_src, w.da_dst, a->att_dst, d_a_dst_out ? nullptr : d_hp, NS, N,
+                           g->dst_offset, H, C, geo.Cp, geo.Dp, w.colsum);
         GATMI_HIP(hipGetLastError());
         if (d_att_src || d_att_dst || d_bias) {
             const int tot = 3 * H * C;
@@ -794,6 +825,24 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
                                w.colsum, blocks, H, C, geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
             GATMI_HIP(hipGetLastError());
         }
+        if (d_a_dst_out)
+            GATMI_HIP(hipMemcpyAsync(d_a_dst_out, w.da_dst, (size_t)N * H * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
     }
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float *d_a_dst,
+                                  const float *att_dst, void *stream) {
+    GATMI_REQUIRE(s && d_hp && d_a_dst && att_dst, "null argument");
+    Geometry geo;
+    if (int e = make_geometry(*s, &geo)) return e;
+    const long long total = (long long)s->num_nodes * s->heads * geo.lph;
+    if (total == 0) return GATMI_OK;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(add_dst_term_kernel, dim3(blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_hp, d_a_dst, att_dst,
+                       (long long)s->num_nodes, s->heads, s->channels, geo.Cp);
+    GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }

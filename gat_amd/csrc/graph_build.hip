@@ -17,14 +17,15 @@
 
 namespace gatmi {
 
-__global__ void gb_make_keys(const int64_t *ei, long long E, long long N, int asl, uint32_t *keys,
-                             uint32_t *vals, uint32_t *selfflag, int *err) {
+__global__ void gb_make_keys(const int64_t *ei, long long E, long long NS, long long N, int asl,
+                             uint32_t *keys, uint32_t *vals, uint32_t *selfflag, int *err) {
+    // NS = source rows, N = destination rows (equal unless the graph is a partition)
     const long long M = E + (asl ? N : 0);
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < M;
          e += (long long)gridDim.x * blockDim.x) {
         if (e < E) {
             const long long s = ei[e], d = ei[E + e];
-            const bool bad = s < 0 || s >= N || d < 0 || d >= N;
+            const bool bad = s < 0 || s >= NS || d < 0 || d >= N;
             if (bad) atomicOr(err, 1);
             const bool self = asl && s == d;
             keys[e] = bad ? (uint32_t)N : (self ? (uint32_t)N : (uint32_t)d);
@@ -158,8 +159,9 @@ struct BuildWs {
     size_t temp_bytes, total;
 };
 
-static BuildWs carve_build(long long E, long long N, int asl, void *ws) {
-    const size_t M = (size_t)(E + (asl ? N : 0));
+static BuildWs carve_build(long long E, long long NS, long long ND, int asl, void *ws) {
+    const long long N = NS > ND ? NS : ND;
+    const size_t M = (size_t)(E + (asl ? ND : 0));
     Carver cv(ws);
     BuildWs w;
     w.keys_a = cv.take<uint32_t>(M);
@@ -219,26 +221,29 @@ static int build_plan(const int *rowptr, int nrows, int seg, gatmi_plan *plan, B
 
 using namespace gatmi;
 
-extern "C" int gatmi_graph_sizes_query(int64_t E, int64_t N, int asl, int seg_len,
+extern "C" int gatmi_graph_sizes_query(int64_t E, int64_t NS, int64_t ND, int asl, int seg_len,
                                        gatmi_graph_sizes *out) {
     GATMI_REQUIRE(out, "null out");
-    GATMI_REQUIRE(E >= 0 && N >= 0 && seg_len >= 64 && seg_len % 64 == 0,
-                  "bad E=%lld N=%lld seg_len=%d", (long long)E, (long long)N, seg_len);
-    GATMI_REQUIRE(E + N < (1ll << 31) - 1, "E + N = %lld does not fit int32 indices",
-                  (long long)(E + N));
-    const int64_t M = E + (asl ? N : 0);
+    GATMI_REQUIRE(E >= 0 && NS >= 0 && ND >= 0 && seg_len >= 64 && seg_len % 64 == 0,
+                  "bad E=%lld num_src=%lld num_dst=%lld seg_len=%d", (long long)E, (long long)NS,
+                  (long long)ND, seg_len);
+    GATMI_REQUIRE(!asl || NS == ND, "add_self_loops needs a square graph (num_src == num_dst)");
+    GATMI_REQUIRE(E + NS + ND < (1ll << 31) - 1, "E + N = %lld does not fit int32 indices",
+                  (long long)(E + NS + ND));
+    const int64_t M = E + (asl ? ND : 0);
+    const int64_t NM = NS > ND ? NS : ND;
     out->max_edges = M;
-    out->max_items = M / seg_len + N + 1;
+    out->max_items = M / seg_len + NM + 1;
     out->max_split_rows = M / seg_len + 1;
-    out->workspace_bytes = (int64_t)carve_build(E, N, asl, nullptr).total;
+    out->workspace_bytes = (int64_t)carve_build(E, NS, ND, asl, nullptr).total;
     return GATMI_OK;
 }
 
-extern "C" int gatmi_graph_build(const int64_t *edge_index, int64_t E, int64_t N, int asl,
-                                 int seg_len, gatmi_graph *g, void *ws, size_t ws_bytes,
+extern "C" int gatmi_graph_build(const int64_t *edge_index, int64_t E, int64_t NS, int64_t ND,
+                                 int asl, int seg_len, gatmi_graph *g, void *ws, size_t ws_bytes,
                                  void *stream) {
     gatmi_graph_sizes sz;
-    if (int e = gatmi_graph_sizes_query(E, N, asl, seg_len, &sz)) return e;
+    if (int e = gatmi_graph_sizes_query(E, NS, ND, asl, seg_len, &sz)) return e;
     GATMI_REQUIRE(g && (edge_index || E == 0), "null graph / edge_index");
     if (ws_bytes < (size_t)sz.workspace_bytes) {
         set_error("graph_build workspace too small: %zu < %lld", ws_bytes,
@@ -246,13 +251,14 @@ extern "C" int gatmi_graph_build(const int64_t *edge_index, int64_t E, int64_t N
         return GATMI_ERR_WS;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    BuildWs w = carve_build(E, N, asl, ws);
-    const long long M = E + (asl ? N : 0);
+    BuildWs w = carve_build(E, NS, ND, asl, ws);
+    const long long M = E + (asl ? ND : 0);
     int *col = const_cast<int *>(g->col), *perm = const_cast<int *>(g->perm);
     int *rowptr = const_cast<int *>(g->rowptr), *rowptr_t = const_cast<int *>(g->rowptr_t);
     int *col_t = const_cast<int *>(g->col_t), *pos_t = const_cast<int *>(g->pos_t);
     int *d2s = const_cast<int *>(g->d2s);
-    g->num_nodes = (int)N;
+    g->num_src = (int)NS;
+    g->num_dst = (int)ND;
     g->seg_len = seg_len;
 
     GATMI_HIP(hipMemsetAsync(w.counts, 0, 16 * sizeof(int), st));
@@ -260,8 +266,8 @@ extern "C" int gatmi_graph_build(const int64_t *edge_index, int64_t E, int64_t N
     int ep = 0;
     if (M > 0) {
         hipLaunchKernelGGL(gb_make_keys, dim3(grid_for(M)), dim3(256), 0, st, edge_index,
-                           (long long)E, (long long)N, asl, w.keys_a, w.vals_a, w.selfflag,
-                           w.counts + 8);
+                           (long long)E, (long long)NS, (long long)ND, asl, w.keys_a, w.vals_a,
+                           w.selfflag, w.counts + 8);
         GATMI_HIP(hipGetLastError());
         size_t tb = w.temp_bytes;
         GATMI_HIP(rocprim::exclusive_scan(w.temp, tb, w.selfflag, w.selfrank, 0u, (size_t)E + 1,
@@ -269,32 +275,33 @@ extern "C" int gatmi_graph_build(const int64_t *edge_index, int64_t E, int64_t N
         hipLaunchKernelGGL(gb_count_self, dim3(1), dim3(64), 0, st, w.selfflag, w.selfrank,
                            (long long)E, w.counts);
         unsigned bits = 1;
-        while ((1ull << bits) <= (unsigned long long)N) ++bits;
+        while ((1ull << bits) <= (unsigned long long)ND) ++bits;
         tb = w.temp_bytes;
         GATMI_HIP(rocprim::radix_sort_pairs(w.temp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b,
                                             (size_t)M, 0u, bits, st));
         hipLaunchKernelGGL(gb_fill_csr, dim3(grid_for(M)), dim3(256), 0, st, edge_index,
-                           (long long)E, (long long)N, M, w.keys_b, w.vals_b, w.selfrank, w.counts,
+                           (long long)E, (long long)ND, M, w.keys_b, w.vals_b, w.selfrank, w.counts,
                            col, perm, w.rowid);
         GATMI_HIP(hipGetLastError());
         int h[16];
         GATMI_HIP(hipMemcpyAsync(h, w.counts, sizeof(h), hipMemcpyDeviceToHost, st));
         GATMI_HIP(hipStreamSynchronize(st));
         if (h[8]) {
-            set_error("edge_index holds a node id outside [0, %lld)", (long long)N);
+            set_error("edge_index holds a node id outside [0, %lld) x [0, %lld)", (long long)NS,
+                      (long long)ND);
             return GATMI_ERR_RANGE;
         }
         ep = (int)(M - h[0]);
     }
     g->num_edges = ep;
-    hipLaunchKernelGGL(gb_rowptr, dim3(grid_for(N + 1)), dim3(256), 0, st, w.keys_b, (long long)ep,
-                       (long long)N, rowptr);
+    hipLaunchKernelGGL(gb_rowptr, dim3(grid_for(ND + 1)), dim3(256), 0, st, w.keys_b, (long long)ep,
+                       (long long)ND, rowptr);
     GATMI_HIP(hipGetLastError());
     if (ep > 0) {
         hipLaunchKernelGGL(gb_iota_keys, dim3(grid_for(ep)), dim3(256), 0, st, col, (long long)ep,
                            w.keys_a, w.vals_a);
         unsigned bits = 1;
-        while ((1ull << bits) <= (unsigned long long)N) ++bits;
+        while ((1ull << bits) <= (unsigned long long)NS) ++bits;
         size_t tb = w.temp_bytes;
         GATMI_HIP(rocprim::radix_sort_pairs(w.temp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b,
                                             (size_t)ep, 0u, bits, st));
@@ -302,11 +309,11 @@ extern "C" int gatmi_graph_build(const int64_t *edge_index, int64_t E, int64_t N
                            w.rowid, (long long)ep, col_t, pos_t, d2s);
         GATMI_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(gb_rowptr, dim3(grid_for(N + 1)), dim3(256), 0, st, w.keys_b, (long long)ep,
-                       (long long)N, rowptr_t);
+    hipLaunchKernelGGL(gb_rowptr, dim3(grid_for(NS + 1)), dim3(256), 0, st, w.keys_b, (long long)ep,
+                       (long long)NS, rowptr_t);
     GATMI_HIP(hipGetLastError());
-    if (int e = build_plan(rowptr, (int)N, seg_len, &g->plan, w, w.counts, st)) return e;
-    if (int e = build_plan(rowptr_t, (int)N, seg_len, &g->plan_t, w, w.counts + 4, st)) return e;
+    if (int e = build_plan(rowptr, (int)ND, seg_len, &g->plan, w, w.counts, st)) return e;
+    if (int e = build_plan(rowptr_t, (int)NS, seg_len, &g->plan_t, w, w.counts + 4, st)) return e;
     GATMI_HIP(hipStreamSynchronize(st));
     return GATMI_OK;
 }

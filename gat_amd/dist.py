@@ -1,0 +1,275 @@
+"""Destination-partitioned GAT layer over several GPUs (BASELINE.json
+config 5): one process per GPU, torch.distributed over RCCL ("nccl" backend) on xGMI.
+
+The reference is single-process (no torch.distributed anywhere in /root/reference); what
+is partitioned here is its one layer call, /root/reference/gat/model.py:40,43,46, on a
+graph too large or too slow for one GPU.  Softmax and aggregation are independent per
+destination node, so rank r owns a contiguous block of destinations, their rows of x and
+the in-edges of those destinations:
+
+  forward   project own rows -> ALL-GATHER h (the one exchange step) -> fused attention
+            over the own destination rows (sources are global ids into the gathered h)
+  backward  fused backward over the own edges -> partial d_h for ALL sources ->
+            REDUCE-SCATTER d_h (adjoint of the all-gather) -> + d_a_dst att_dst on own rows
+            -> own d_x and partial d_W -> ALL-REDUCE of d_W, d_att_src, d_att_dst, d_bias
+
+Blocks are equal (B = ceil(N / P) nodes, the last ones shorter or empty) so the
+collectives are the plain equal-shard forms.  The compute steps go through a small backend
+object: `HipBackend` is the product (C ABI, GPU only); tests swap in a CPU stand-in to
+check the partition + collective algebra under gloo.
+"""
+from __future__ import annotations
+
+import json
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import _lib
+
+
+@dataclass
+class Partition:
+    num_nodes: int
+    world: int
+    rank: int
+
+    @property
+    def block(self) -> int:
+        return (self.num_nodes + self.world - 1) // self.world
+
+    @property
+    def lo(self) -> int:
+        return min(self.rank * self.block, self.num_nodes)
+
+    @property
+    def hi(self) -> int:
+        return min(self.lo + self.block, self.num_nodes)
+
+    @property
+    def n_local(self) -> int:
+        return self.hi - self.lo
+
+    @property
+    def padded_nodes(self) -> int:
+        return self.block * self.world
+
+
+def local_edges(edge_index: Tensor, part: Partition) -> Tensor:
+    """This rank's share of the NORMALISED edge list: in-edges of its destinations in their
+    original order with self-loops removed, then one loop per own node (exactly what
+    remove_self_loops + add_self_loops leaves for those destinations).  Row 0 keeps global
+    source ids, row 1 becomes local destination ids."""
+    src, dst = edge_index[0], edge_index[1]
+    keep = (dst >= part.lo) & (dst < part.hi) & (src != dst)
+    loops = torch.arange(part.lo, part.hi, dtype=edge_index.dtype, device=edge_index.device)
+    return torch.stack([torch.cat([src[keep], loops]),
+                        torch.cat([dst[keep] - part.lo, loops - part.lo])])
+
+
+# ------------------------------------------------------------------ collectives
+def all_gather_rows(shard: Tensor, world: int, group=None) -> Tensor:
+    out = shard.new_empty((world * shard.size(0),) + tuple(shard.shape[1:]))
+    try:
+        dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):   # backends without the flat form
+        dist.all_gather(list(out.chunk(world, 0)), shard.contiguous(), group=group)
+    return out
+
+
+def reduce_scatter_rows(full: Tensor, world: int, rank: int, group=None) -> Tensor:
+    out = full.new_empty((full.size(0) // world,) + tuple(full.shape[1:]))
+    if dist.get_backend(group) == "gloo":         # gloo has no reduce-scatter: reduce, then slice
+        tmp = full.clone()
+        dist.all_reduce(tmp, group=group)
+        out.copy_(tmp.chunk(world, 0)[rank])
+    else:
+        dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
+    return out
+
+
+def all_reduce_many(tensors, group=None) -> None:
+    """one all-reduce for several small gradients (latency-bound: pack them)."""
+    live = [t for t in tensors if t is not None]
+    flat = torch.cat([t.reshape(-1) for t in live])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for t in live:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+
+
+# ------------------------------------------------------------------ compute backend
+class HipBackend:
+    """The product path: libgat_mi355.so through gat_amd.ops."""
+
+    def __init__(self, seg_len: int = 512):
+        self.seg_len = seg_len
+
+    def build_layout(self, local_ei: Tensor, part: Partition):
+        from .graph import build_graph
+        return build_graph(local_ei, part.padded_nodes, add_self_loops=False, seg_len=self.seg_len,
+                           num_dst=part.n_local, dst_offset=part.lo)
+
+    def project_fwd(self, x, w, att_d, cfg):
+        from . import ops
+        return ops.project_fwd(x, w, att_d, cfg.heads, cfg.channels)
+
+    def attn_fwd(self, layout, cfg, f, hp_full, a_dst, att_s, att_d, bias, need_lse):
+        from . import ops
+        return ops.attn_fwd(layout, cfg, f, hp_full, a_dst, att_s, att_d, bias, need_lse)
+
+    def attn_bwd(self, layout, cfg, f, hp_full, a_dst, att_s, att_d, bias, out, lse, grad_out):
+        from . import ops
+        return ops.attn_bwd(layout, cfg, f, hp_full, a_dst, att_s, att_d, bias, out, lse, grad_out,
+                            defer_dst_term=True)
+
+    def add_dst_term(self, d_hp, d_a_dst, att_d, cfg):
+        from . import ops
+        ops.add_dst_term(d_hp, d_a_dst, att_d, cfg.heads, cfg.channels)
+
+    def project_bwd(self, x, w, d_hp, cfg, need_dx):
+        from . import ops
+        return ops.project_bwd(x, w, d_hp, cfg.heads, cfg.channels, need_dx)
+
+
+class _PartitionedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, weight, att_src, att_dst, bias, part, layout, cfg, be, group):
+        x_local, weight = x_local.contiguous(), weight.contiguous()
+        att_s, att_d = att_src.contiguous().view(-1), att_dst.contiguous().view(-1)
+        bias_c = None if bias is None else bias.contiguous()
+        f = x_local.size(1)
+        hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
+        shard = hp_local
+        if part.n_local < part.block:            # short / empty last block: pad to B rows
+            shard = hp_local.new_zeros(part.block, hp_local.size(1))
+            shard[:part.n_local] = hp_local
+        hp_full = all_gather_rows(shard, part.world, group)
+        need_grad = any(ctx.needs_input_grad[:5])
+        out, lse = be.attn_fwd(layout, cfg, f, hp_full, a_dst, att_s, att_d, bias_c, need_grad)
+        if need_grad:
+            ctx.save_for_backward(x_local, weight, att_s, att_d, bias_c, hp_full, a_dst, out, lse)
+            ctx.misc = (part, layout, cfg, be, group, att_src.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_local, weight, att_s, att_d, bias_c, hp_full, a_dst, out, lse = ctx.saved_tensors
+        part, layout, cfg, be, group, att_shape = ctx.misc
+        d_hp_part, d_as, d_ad, d_b, d_a_dst = be.attn_bwd(
+            layout, cfg, x_local.size(1), hp_full, a_dst, att_s, att_d, bias_c, out, lse,
+            grad_out.contiguous())
+        d_hp = reduce_scatter_rows(d_hp_part, part.world, part.rank, group)[:part.n_local]
+        d_hp = d_hp.contiguous()
+        be.add_dst_term(d_hp, d_a_dst, att_d, cfg)
+        d_w, d_x = be.project_bwd(x_local, weight, d_hp, cfg, ctx.needs_input_grad[0])
+        all_reduce_many([d_w, d_as, d_ad, d_b], group)
+        return (d_x, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
+                None, None, None, None, None)
+
+
+class PartitionedGATConv(nn.Module):
+    """GATConv (model.py:26,28,30) whose forward takes this rank's rows of x.  Parameters
+    are replicated (same seed / broadcast by the caller); their gradients come back
+    all-reduced, so every rank steps identically."""
+
+    def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, dropout=0.0,
+                 bias=True, backend=None, group=None):
+        super().__init__()
+        from .layer import _glorot_
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.negative_slope, self.dropout = negative_slope, dropout
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels)) if bias else None
+        _glorot_(self.lin.weight), _glorot_(self.att_src), _glorot_(self.att_dst)
+        self.backend = backend or HipBackend()
+        self.group = group
+        self._layouts = {}
+
+    def layout_for(self, edge_index: Tensor, part: Partition):
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, part.rank)
+        if key not in self._layouts:
+            self._layouts = {key: self.backend.build_layout(local_edges(edge_index, part), part)}
+        return self._layouts[key]
+
+    def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
+        from .ops import AttnConfig
+        world = dist.get_world_size(self.group)
+        part = Partition(num_nodes, world, dist.get_rank(self.group))
+        if x_local.size(0) != part.n_local:
+            raise ValueError(f"rank {part.rank} owns nodes [{part.lo}, {part.hi}) but got "
+                             f"{x_local.size(0)} rows of x")
+        layout = self.layout_for(edge_index, part)
+        mask_mode, seed = _lib.MASK_NONE, 0
+        if self.training and self.dropout > 0.0:
+            mask_mode = _lib.MASK_HASH
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) + part.rank
+        cfg = AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
+                         mask_mode, seed, None)
+        return _PartitionedFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
+                                    self.bias, part, layout, cfg, self.backend, self.group)
+
+
+# ------------------------------------------------------------------ bench.py --gpus N
+def bench_partitioned(args, rank: int, world: int, dev) -> None:
+    """One products-shaped layer, destination-partitioned over `world` GPUs; rank 0 prints
+    bench.py's JSON line.  Every rank regenerates the same graph from the seed and keeps
+    its own block."""
+    from . import synth
+    ei, n, f, h, c = synth.workload_graph(args.workload, args.seed, dev)
+    part = Partition(n, world, rank)
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    x = torch.randn(n, f, generator=g, device=dev)[part.lo:part.hi].contiguous()
+    torch.manual_seed(args.seed)
+    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout).to(dev).train()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    layout = conv.layout_for(ei, part)
+    torch.cuda.synchronize()
+    t_layout = time.time() - t0
+    edges = torch.tensor([layout.num_edges], device=dev, dtype=torch.int64)
+    dist.all_reduce(edges)
+    ep = int(edges.item())
+    go = torch.randn(part.n_local, h * c, generator=g, device=dev)
+
+    def step():
+        conv.zero_grad(set_to_none=True)
+        out = conv(x, ei, n)
+        out.backward(go)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
+               "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
+                                      f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
+                                      f"layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
+                          "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
+                          "parallelism": f"destination partition x{world}: all-gather(h) fwd, "
+                                         f"reduce-scatter(d_h) + all-reduce(param grads) bwd, RCCL",
+                          "graph_layout_build_s": round(t_layout, 4)},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(res))
+    dist.destroy_process_group()

@@ -25,7 +25,8 @@ class GraphLayout:
         self.desc = desc
         self._t = tensors  # keeps the device memory behind `desc` alive
         self.device = device
-        self.num_nodes = int(desc.num_nodes)
+        self.num_nodes = int(desc.num_src)
+        self.num_dst = int(desc.num_dst)
         self.num_edges = int(desc.num_edges)
         self.seg_len = int(desc.seg_len)
 
@@ -49,7 +50,11 @@ def _stream_ptr(device) -> int:
 
 
 def build_graph(edge_index: torch.Tensor, num_nodes: int, add_self_loops: bool = True,
-                seg_len: int = DEFAULT_SEG_LEN) -> GraphLayout:
+                seg_len: int = DEFAULT_SEG_LEN, num_dst: int = None,
+                dst_offset: int = 0) -> GraphLayout:
+    """num_dst/dst_offset describe a destination partition: edge_index[1] then holds LOCAL
+    destination ids in [0, num_dst), edge_index[0] global source ids in [0, num_nodes)."""
+    num_dst = num_nodes if num_dst is None else num_dst
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
     if edge_index.dtype != torch.int64:
@@ -61,11 +66,11 @@ def build_graph(edge_index: torch.Tensor, num_nodes: int, add_self_loops: bool =
     ei = edge_index.contiguous()
     e = ei.size(1)
     sizes = _lib.GraphSizes()
-    _lib.check(lib.gatmi_graph_sizes_query(e, num_nodes, int(add_self_loops), seg_len,
+    _lib.check(lib.gatmi_graph_sizes_query(e, num_nodes, num_dst, int(add_self_loops), seg_len,
                                            C.byref(sizes)), "gatmi_graph_sizes_query")
     with torch.cuda.device(dev):
         i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
-        t = dict(rowptr=i32(num_nodes + 1), col=i32(sizes.max_edges), perm=i32(sizes.max_edges),
+        t = dict(rowptr=i32(num_dst + 1), col=i32(sizes.max_edges), perm=i32(sizes.max_edges),
                  rowptr_t=i32(num_nodes + 1), col_t=i32(sizes.max_edges),
                  pos_t=i32(sizes.max_edges), d2s=i32(sizes.max_edges))
         for p in ("plan", "plan_t"):
@@ -81,9 +86,10 @@ def build_graph(edge_index: torch.Tensor, num_nodes: int, add_self_loops: bool =
         for p, plan in (("plan", g.plan), ("plan_t", g.plan_t)):
             for k in ("item_row", "item_beg", "item_slot", "split_row", "split_slot"):
                 setattr(plan, k, t[f"{p}.{k}"].data_ptr())
-        _lib.check(lib.gatmi_graph_build(ei.data_ptr(), e, num_nodes, int(add_self_loops), seg_len,
-                                         C.byref(g), ws.data_ptr(), ws.numel(), _stream_ptr(dev)),
-                   "gatmi_graph_build")
+        _lib.check(lib.gatmi_graph_build(ei.data_ptr(), e, num_nodes, num_dst, int(add_self_loops),
+                                         seg_len, C.byref(g), ws.data_ptr(), ws.numel(),
+                                         _stream_ptr(dev)), "gatmi_graph_build")
+        g.dst_offset = dst_offset
     ep = int(g.num_edges)
     for k in ("col", "perm", "col_t", "pos_t", "d2s"):
         t[k] = t[k][:ep]

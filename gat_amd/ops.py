@@ -1,0 +1,125 @@
+"""Tensor-level wrappers of the C ABI (include/gat_mi355.h): each function allocates its
+outputs and workspace with torch, passes raw device pointers and the current stream to
+libgat_mi355.so, and raises RuntimeError on a non-zero status.  GPU only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .graph import GraphLayout
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ws(nbytes: int, dev) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def padded_channels(channels: int) -> int:
+    return (channels + 3) // 4 * 4
+
+
+class AttnConfig:
+    """Everything the fused attention kernels need besides tensors."""
+
+    def __init__(self, heads: int, channels: int, negative_slope: float = 0.2, dropout: float = 0.0,
+                 mask_mode: int = _lib.MASK_NONE, seed: int = 0, mask: Optional[Tensor] = None):
+        self.heads, self.channels = heads, channels
+        self.negative_slope, self.dropout = float(negative_slope), float(dropout)
+        self.mask_mode, self.seed, self.mask = mask_mode, seed, mask
+
+    def c_args(self, num_dst, in_features, hp, a_dst, att_src, att_dst, bias):
+        a = _lib.Attn()
+        a.shape = _lib.Shape(num_dst, in_features, self.heads, self.channels)
+        a.negative_slope, a.dropout_p = self.negative_slope, self.dropout
+        a.mask_mode, a.seed, a.mask = self.mask_mode, self.seed, _ptr(self.mask)
+        a.hp, a.a_dst = _ptr(hp), _ptr(a_dst)
+        a.att_src, a.att_dst, a.bias = _ptr(att_src), _ptr(att_dst), _ptr(bias)
+        return a
+
+
+def project_fwd(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int
+                ) -> Tuple[Tensor, Tensor]:
+    """h = lin(x) in the head-padded layout [N, H*Cp] and a_dst [N, H]."""
+    lib, dev = _lib.lib(), x.device
+    n, f = x.shape
+    shape = _lib.Shape(n, f, heads, channels)
+    with torch.cuda.device(dev):
+        hp = torch.empty(n, heads * padded_channels(channels), dtype=torch.float32, device=dev)
+        a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
+        ws = _ws(lib.gatmi_project_workspace_bytes(C.byref(shape)), dev)
+        _lib.check(lib.gatmi_project_fwd(C.byref(shape), x.data_ptr(), weight.data_ptr(),
+                                         att_dst.data_ptr(), hp.data_ptr(), a_dst.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream(dev)), "gatmi_project_fwd")
+    return hp, a_dst
+
+
+def project_bwd(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channels: int,
+                need_dx: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    lib, dev = _lib.lib(), x.device
+    n, f = x.shape
+    shape = _lib.Shape(n, f, heads, channels)
+    with torch.cuda.device(dev):
+        d_w = torch.empty_like(weight)
+        d_x = torch.empty_like(x) if need_dx else None
+        ws = _ws(lib.gatmi_project_workspace_bytes(C.byref(shape)), dev)
+        _lib.check(lib.gatmi_project_bwd(C.byref(shape), x.data_ptr(), weight.data_ptr(),
+                                         d_hp.data_ptr(), d_w.data_ptr(), _ptr(d_x),
+                                         ws.data_ptr(), ws.numel(), _stream(dev)), "gatmi_project_bwd")
+    return d_w, d_x
+
+
+def attn_fwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor, a_dst: Tensor,
+             att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], need_lse: bool
+             ) -> Tuple[Tensor, Optional[Tensor]]:
+    """out [num_dst, H*C] (+ lse [num_dst, H] when a backward will follow)."""
+    lib, dev = _lib.lib(), hp.device
+    n = layout.num_dst
+    with torch.cuda.device(dev):
+        a = cfg.c_args(n, in_features, hp, a_dst, att_src, att_dst, bias)
+        out = torch.empty(n, cfg.heads * cfg.channels, dtype=torch.float32, device=dev)
+        lse = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev) if need_lse else None
+        ws = _ws(lib.gatmi_attn_fwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
+        _lib.check(lib.gatmi_attn_fwd(layout.ref, C.byref(a), out.data_ptr(), _ptr(lse),
+                                      ws.data_ptr(), ws.numel(), _stream(dev)), "gatmi_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor, a_dst: Tensor,
+             att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], out: Tensor, lse: Tensor,
+             grad_out: Tensor, defer_dst_term: bool = False):
+    """-> d_hp [num_src, Dp], d_att_src, d_att_dst, d_bias, d_a_dst (None unless deferred)."""
+    lib, dev = _lib.lib(), hp.device
+    with torch.cuda.device(dev):
+        a = cfg.c_args(layout.num_dst, in_features, hp, a_dst, att_src, att_dst, bias)
+        d_hp = torch.empty(layout.num_nodes, hp.size(1), dtype=torch.float32, device=dev)
+        d_as = torch.empty_like(att_src)
+        d_ad = torch.empty_like(att_dst)
+        d_b = torch.empty_like(bias) if bias is not None else None
+        d_a_dst = (torch.empty(layout.num_dst, cfg.heads, dtype=torch.float32, device=dev)
+                   if defer_dst_term else None)
+        ws = _ws(lib.gatmi_attn_bwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
+        _lib.check(lib.gatmi_attn_bwd(layout.ref, C.byref(a), out.data_ptr(), lse.data_ptr(),
+                                      grad_out.data_ptr(), d_hp.data_ptr(), d_as.data_ptr(),
+                                      d_ad.data_ptr(), _ptr(d_b), _ptr(d_a_dst), ws.data_ptr(),
+                                      ws.numel(), _stream(dev)), "gatmi_attn_bwd")
+    return d_hp, d_as, d_ad, d_b, d_a_dst
+
+
+def add_dst_term(d_hp: Tensor, d_a_dst: Tensor, att_dst: Tensor, heads: int, channels: int) -> None:
+    """d_hp[i,h,:] += d_a_dst[i,h] * att_dst[h,:] in place (rows of one shard)."""
+    lib, dev = _lib.lib(), d_hp.device
+    shape = _lib.Shape(d_hp.size(0), 1, heads, channels)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gatmi_add_dst_term(C.byref(shape), d_hp.data_ptr(), d_a_dst.data_ptr(),
+                                          att_dst.data_ptr(), _stream(dev)), "gatmi_add_dst_term")

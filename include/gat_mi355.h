@@ -77,9 +77,11 @@ typedef struct gatmi_plan {
  *   rowptr_t/col_t : same edges grouped by source (col_t = destination), ordered by e
  *   pos_t[t] : dst-CSR position of transposed edge t;   d2s[e] : its inverse        */
 typedef struct gatmi_graph {
-    int32_t num_nodes;
-    int32_t num_edges; /* E' */
+    int32_t num_src;    /* rows of the feature table the edges gather from (all nodes)      */
+    int32_t num_dst;    /* destination rows; == num_src except for a destination partition  */
+    int32_t num_edges;  /* E' */
     int32_t seg_len;
+    int32_t dst_offset; /* partition only: source id of destination row 0 (set by caller)   */
     int32_t _pad;
     const int32_t *rowptr, *col, *perm;
     const int32_t *rowptr_t, *col_t, *pos_t, *d2s;
@@ -95,14 +97,18 @@ typedef struct gatmi_graph_sizes {
     int64_t workspace_bytes;
 } gatmi_graph_sizes;
 
-int gatmi_graph_sizes_query(int64_t num_edges, int64_t num_nodes, int add_self_loops,
-                            int seg_len, gatmi_graph_sizes *out /* host */);
+int gatmi_graph_sizes_query(int64_t num_edges, int64_t num_src, int64_t num_dst,
+                            int add_self_loops, int seg_len, gatmi_graph_sizes *out /* host */);
 
 /* Fills the arrays `g` points to (caller-allocated to the bounds above; the const is
  * cast away) and sets the counts in *g (host struct).  edge_index: int64 [2, E].
- * Synchronises `stream` before returning. */
-int gatmi_graph_build(const int64_t *edge_index, int64_t num_edges, int64_t num_nodes,
-                      int add_self_loops, int seg_len, gatmi_graph *g /* host */,
+ * Synchronises `stream` before returning.
+ * A destination partition (one GPU's share of a large graph) is the
+ * rectangular case: sources 0..num_src-1 are all nodes, destinations 0..num_dst-1 are
+ * the partition's own nodes renumbered from 0; add_self_loops must then be 0 (the
+ * partitioner appends each own node's loop itself). */
+int gatmi_graph_build(const int64_t *edge_index, int64_t num_edges, int64_t num_src,
+                      int64_t num_dst, int add_self_loops, int seg_len, gatmi_graph *g /* host */,
                       void *ws, size_t ws_bytes, void *stream);
 
 /* Shape of one layer.  C = out_channels per head, Cp = round_up(C, 4). */
@@ -156,16 +162,25 @@ int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *out, float 
 int gatmi_dropout_mask(const gatmi_graph *g, int heads, float dropout_p, uint64_t seed,
                        uint8_t *mask, void *stream);
 
-/* Backward of rows a6-a10 (row a11): pass A over the dst-CSR (softmax/LeakyReLU
- * gradients, d a_dst), pass B over the transposed CSR (d h gather-accumulate, d a_src),
- * then the column reductions for d att_src, d att_dst, d bias.
- *   out, lse : what gatmi_attn_fwd produced;  grad_out [N, H*C]
- *   -> d_hp [N, Dp], d_att_src [H*C], d_att_dst [H*C], d_bias [H*C] (NULL to skip)     */
+/* Backward of rows a6-a10 (row a11): a per-node preparation, ONE pass over the
+ * transposed CSR that gathers each grad_out row once and does all per-edge work
+ * (softmax/LeakyReLU/dropout gradients, d h accumulation, d a_src), a light pass over the
+ * dst-CSR for d a_dst, then the column reductions for d att_src, d att_dst, d bias.
+ *   out, lse : what gatmi_attn_fwd produced;  grad_out [num_dst, H*C]
+ *   -> d_hp [num_src, Dp], d_att_src [H*C], d_att_dst [H*C], d_bias [H*C] (NULL to skip)
+ * d_a_dst_out == NULL (square graphs only): d_hp is complete on return.
+ * d_a_dst_out != NULL: [num_dst, H] receives d a_dst and d_hp lacks the term
+ * d_a_dst[i] * att_dst of its destination rows -- a destination partition adds it with
+ * gatmi_add_dst_term after the reduce-scatter of d_hp. */
 size_t gatmi_attn_bwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
 int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
                    const float *lse, const float *grad_out, float *d_hp,
-                   float *d_att_src, float *d_att_dst, float *d_bias,
+                   float *d_att_src, float *d_att_dst, float *d_bias, float *d_a_dst_out,
                    void *ws, size_t ws_bytes, void *stream);
+
+/* d_hp[i, h, :] += d_a_dst[i, h] * att_dst[h, :] for i < s->num_nodes (rows of one shard). */
+int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float *d_a_dst,
+                       const float *att_dst, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ def test_binding_covers_header():
 def test_struct_layouts_match_c():
     assert ctypes.sizeof(_lib.Shape) == 16
     assert ctypes.sizeof(_lib.Plan) == 16 + 5 * 8
-    assert ctypes.sizeof(_lib.Graph) == 16 + 7 * 8 + 2 * ctypes.sizeof(_lib.Plan)
+    assert ctypes.sizeof(_lib.Graph) == 24 + 7 * 8 + 2 * ctypes.sizeof(_lib.Plan)
     assert ctypes.sizeof(_lib.GraphSizes) == 32
     assert ctypes.sizeof(_lib.Attn) == 16 + 16 + 8 + 6 * 8
     assert _lib.Attn.hp.offset == 48
@@ -55,7 +55,7 @@ def test_version_and_error_string_callable_without_gpu():
 def test_argument_errors_are_reported_not_crashed():
     lib = _lib.lib()
     sizes = _lib.GraphSizes()
-    rc = lib.gatmi_graph_sizes_query(10, 5, 1, 100, ctypes.byref(sizes))  # seg_len not % 64
+    rc = lib.gatmi_graph_sizes_query(10, 5, 5, 1, 100, ctypes.byref(sizes))  # seg_len not % 64
     assert rc == 1 and b"seg_len" in lib.gatmi_last_error()
     with pytest.raises(RuntimeError, match="seg_len"):
         _lib.check(rc, "gatmi_graph_sizes_query")
