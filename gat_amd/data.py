@@ -1,0 +1,76 @@
+"""Graph container and construction on the host, mirroring what the reference feeds its
+model: Data(x, edge_index, y) from /root/reference/gat/converter.py:18-24 with the kNN
+graph of :7-15 (k=5, include_self=True, scikit-learn on the CPU -- one-off, out of the hot
+path)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+
+
+class Data:
+    """x float32 [N, F], edge_index int64 [2, E] (row 0 = source, row 1 = destination),
+    y int64 [N]; num_features == x.size(1) as torch_geometric.data.Data reports it."""
+
+    def __init__(self, x, edge_index, y=None):
+        self.x, self.edge_index, self.y = x, edge_index, y
+
+    @property
+    def num_features(self) -> int:
+        return int(self.x.size(1))
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.x.size(0))
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return Data(mv(self.x), mv(self.edge_index), mv(self.y))
+
+
+def create_knn_graph(X, k: int = 5) -> torch.Tensor:
+    from sklearn.neighbors import kneighbors_graph
+    values = X.values if hasattr(X, "values") else np.asarray(X)
+    adj = kneighbors_graph(values, n_neighbors=k, mode="connectivity", include_self=True,
+                           n_jobs=-1).tocoo()
+    pairs = np.vstack([adj.row.astype(np.int64), adj.col.astype(np.int64)])
+    return torch.tensor(pairs, dtype=torch.long)
+
+
+def convert_to_graph(X, y) -> Data:
+    xv = X.values if hasattr(X, "values") else np.asarray(X)
+    yv = y.values if hasattr(y, "values") else np.asarray(y)
+    return Data(x=torch.tensor(xv, dtype=torch.float), edge_index=create_knn_graph(X),
+                y=torch.tensor(yv, dtype=torch.long))
+
+
+@dataclass
+class Metrics:
+    """Per-epoch curves train_model returns (/root/reference/gat/data_models.py:5-17)."""
+    epoch_values: List[int] = field(default_factory=list)
+    train_loss: List[float] = field(default_factory=list)
+    val_loss: List[float] = field(default_factory=list)
+    train_accuracy: List[float] = field(default_factory=list)
+    val_accuracy: List[float] = field(default_factory=list)
+    train_precision: List[float] = field(default_factory=list)
+    train_recall: List[float] = field(default_factory=list)
+    train_f1: List[float] = field(default_factory=list)
+    val_precision: List[float] = field(default_factory=list)
+    val_recall: List[float] = field(default_factory=list)
+    val_f1: List[float] = field(default_factory=list)
+
+
+def synthetic_traces(num_rows: int = 20000, num_features: int = 25, seed: int = 0):
+    """Stand-in for the absent data/traces.csv (/root/reference/.gitignore:33): features in
+    [0, 1] like the reference's min-max-normalised columns (encoder.py:19,37,49), binary
+    label correlated with a few of them so that training has something to learn."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    x = rng.random((num_rows, num_features)).astype(np.float32)
+    score = 2.5 * x[:, 0] - 1.5 * x[:, 3] + x[:, 7] * x[:, 11] + 0.3 * rng.standard_normal(num_rows)
+    y = (score > np.quantile(score, 0.8)).astype(np.int64)
+    cols = [f"f{i}" for i in range(num_features)]
+    return pd.DataFrame(x, columns=cols), pd.Series(y, name="is_anomaly")

@@ -1,0 +1,188 @@
+"""The reference's network and training loop (/root/reference/gat/model.py:18-133) on
+gat_amd.GATConv: same constructor, forward(data), train_model(train, val) -> Metrics and
+test_model(data).  The three layer calls are the HIP hot path; ELU / BatchNorm / dropout /
+log_softmax / nll_loss / the optimizer stay stock PyTorch-ROCm ops.
+
+Differences a caller can see, all forced by the move to a GPU or to torch 2.10:
+  * the model lives on the GPU (`device`, default cuda:LOCAL_RANK) and moves `data` there
+    once (cached), the reference has no device at all;
+  * ReduceLROnPlateau is built without `verbose=True` (removed in torch 2.10); the learning
+    rate is still printed every epoch as at model.py:112;
+  * precision / recall / F1 come from an on-device confusion matrix (one tiny copy per
+    epoch) with scikit-learn's weighted-average arithmetic, instead of three sklearn calls
+    on .cpu() tensors per epoch (model.py:61-63,76-79);
+  * the checkpoint file name is an attribute (`checkpoint_path`, default "best_model.pth"
+    as at model.py:118) so concurrent trials do not collide.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .data import Data, Metrics
+from .layer import GATConv
+
+
+def default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("gat_amd.model.GAT needs a GPU: the GAT layer has no CPU path")
+    n = max(torch.cuda.device_count(), 1)
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % n)
+
+
+def confusion_counts(y_true: torch.Tensor, y_pred: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """[K, K] int64, rows = true class, columns = predicted (sklearn.confusion_matrix)."""
+    flat = y_true.to(torch.int64) * num_classes + y_pred.to(torch.int64)
+    return torch.bincount(flat, minlength=num_classes * num_classes).view(num_classes, num_classes)
+
+
+def weighted_prf(cm: torch.Tensor):
+    """precision, recall, F1 with average="weighted" and zero_division -> 0, the arithmetic
+    of sklearn.metrics.precision_score & co. as called at model.py:61-63."""
+    cm = cm.to(torch.float64)
+    tp = cm.diag()
+    support, predicted = cm.sum(1), cm.sum(0)
+    total = support.sum().clamp(min=1)
+    prec = torch.where(predicted > 0, tp / predicted.clamp(min=1), torch.zeros_like(tp))
+    rec = torch.where(support > 0, tp / support.clamp(min=1), torch.zeros_like(tp))
+    den = prec + rec
+    f1 = torch.where(den > 0, 2 * prec * rec / den.clamp(min=1e-300), torch.zeros_like(tp))
+    w = support / total
+    return float((prec * w).sum()), float((rec * w).sum()), float((f1 * w).sum())
+
+
+def print_epoch_stats(epoch, seconds, tr, va, cm):
+    """Same lines as /root/reference/gat/analysis.py:112-122."""
+    print(f"Epoch {epoch}, Time: {seconds:.2f}s")
+    print(f"Train Loss: {tr[0]:.4f}, Train Accuracy: {tr[1]:.4f}")
+    print(f"Val Loss: {va[0]:.4f}, Val Accuracy: {va[1]:.4f}")
+    print(f"Train Precision: {tr[2]:.4f}, Train Recall: {tr[3]:.4f}, Train F1-Score: {tr[4]:.4f}")
+    print(f"Validation Precision: {va[2]:.4f}, Validation Recall: {va[3]:.4f}, "
+          f"Validation F1-Score: {va[4]:.4f}")
+    print(f"Confusion Matrix:\n{cm}")
+    print("--------------------------------------------------")
+
+
+class GAT(nn.Module):
+    def __init__(self, optimizer, num_features, num_classes, weight_decay=1e-3, dropout=0.7,
+                 hidden_dim=16, epochs=30, lr=0.005, patience=3, device=None, verbose=True):
+        super().__init__()
+        self.epochs, self.patience, self.num_classes = epochs, patience, num_classes
+        self.verbose = verbose
+        self.checkpoint_path = "best_model.pth"
+        self.conv1 = GATConv(num_features, hidden_dim, heads=8, dropout=dropout)
+        self.bn1 = nn.BatchNorm1d(hidden_dim * 8)
+        self.conv2 = GATConv(hidden_dim * 8, hidden_dim, heads=8, dropout=dropout)
+        self.bn2 = nn.BatchNorm1d(hidden_dim * 8)
+        self.conv3 = GATConv(hidden_dim * 8, num_classes, heads=1, concat=True, dropout=dropout)
+        self.dropout = nn.Dropout(p=dropout)
+        self.device = torch.device(device) if device is not None else default_device()
+        self.to(self.device)
+        self.optimizer = optimizer(self.parameters(), lr=lr, weight_decay=weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
+            self.optimizer, mode="min", factor=0.1, patience=self.patience)
+        self._resident = {}
+
+    # -- data residency: move each Data object to the GPU once
+    def _on_device(self, data) -> Data:
+        if data.x.device == self.device:
+            return data
+        hit = self._resident.get(id(data))
+        if hit is None or hit[0] is not data:
+            hit = (data, Data(data.x, data.edge_index, data.y).to(self.device))
+            self._resident[id(data)] = hit
+        return hit[1]
+
+    def forward(self, data):
+        data = self._on_device(data)
+        x, edge_index = data.x, data.edge_index
+        x = self.dropout(x)
+        x = self.bn1(F.elu(self.conv1(x, edge_index)))
+        x = self.dropout(x)
+        x = self.bn2(F.elu(self.conv2(x, edge_index)))
+        x = self.dropout(x)
+        return F.log_softmax(self.conv3(x, edge_index), dim=1)
+
+    def _scores(self, out, y, loss):
+        preds = out.argmax(dim=1)
+        cm = confusion_counts(y, preds, max(self.num_classes, int(out.size(1)))).cpu()
+        accuracy = float(cm.diag().sum()) / max(int(y.size(0)), 1)
+        return (float(loss), accuracy) + weighted_prf(cm), cm
+
+    def train_epoch(self, data):
+        data = self._on_device(data)
+        self.train()
+        self.optimizer.zero_grad()
+        out = self(data)
+        loss = F.nll_loss(out, data.y)
+        loss.backward()
+        self.optimizer.step()
+        stats, _ = self._scores(out.detach(), data.y, loss.detach())
+        return stats
+
+    def validate_epoch(self, data):
+        data = self._on_device(data)
+        self.eval()
+        with torch.no_grad():
+            out = self(data)
+            stats, cm = self._scores(out, data.y, F.nll_loss(out, data.y))
+        return stats + (cm.numpy(),)
+
+    def train_model(self, train_data, val_data) -> Metrics:
+        metrics = Metrics()
+        best, stale = float("inf"), 0
+        for epoch in range(1, self.epochs + 1):
+            t0 = time.time()
+            tr = self.train_epoch(train_data)
+            *va, cm = self.validate_epoch(val_data)
+            for name, value in zip(("loss", "accuracy", "precision", "recall", "f1"), tr):
+                getattr(metrics, "train_" + name).append(value)
+            for name, value in zip(("loss", "accuracy", "precision", "recall", "f1"), va):
+                getattr(metrics, "val_" + name).append(value)
+            metrics.epoch_values.append(epoch)
+            if self.verbose:
+                print_epoch_stats(epoch, time.time() - t0, tr, va, cm)
+            self.scheduler.step(va[0])
+            if self.verbose:
+                print(f"Epoch {epoch}, Current Learning Rate: "
+                      f'{self.scheduler.optimizer.param_groups[0]["lr"]}')
+            if va[0] < best:
+                best, stale = va[0], 0
+                torch.save(self.state_dict(), self.checkpoint_path)
+            else:
+                stale += 1
+                if stale >= self.patience:
+                    if self.verbose:
+                        print("Early stopping")
+                    break
+        if os.path.exists(self.checkpoint_path):
+            self.load_state_dict(torch.load(self.checkpoint_path, map_location=self.device))
+        plot_metrics(metrics)
+        return metrics
+
+    def test_model(self, data):
+        self.eval()
+        return self(data).argmax(dim=1)
+
+
+def plot_metrics(metrics: Metrics, path: str = "./results/accuracy_over_epochs.png") -> None:
+    """Accuracy-over-epoch plot of /root/reference/gat/analysis.py:124-157; skipped quietly
+    when matplotlib or the results directory is missing (reporting is out of the hot path)."""
+    if not os.path.isdir(os.path.dirname(path)):
+        return
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:  # noqa: BLE001
+        return
+    _, ax = plt.subplots(figsize=(12, 8))
+    ax.plot(metrics.epoch_values, metrics.train_accuracy, "o-r", label="Train Accuracy")
+    ax.plot(metrics.epoch_values, metrics.val_accuracy, "s--r", label="Val Accuracy")
+    ax.set_xlabel("Epoch"), ax.set_ylabel("Metrics"), ax.set_title("Accuracy over Epoch")
+    ax.grid(True, linestyle="--", linewidth=0.7), ax.legend()
+    plt.tight_layout(), plt.savefig(path), plt.close()
