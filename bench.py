@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.425)  # run.py:21, attention dropout on
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "h", "x"],
+                    help="N>1: what the destination partition all-gathers (gat_amd/dist.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -12,6 +12,8 @@ the in-edges of those destinations:
   backward  fused backward over the own edges -> partial d_h for ALL sources ->
             REDUCE-SCATTER d_h (adjoint of the all-gather) -> + d_a_dst att_dst on own rows
             -> own d_x and partial d_W -> ALL-REDUCE of d_W, d_att_src, d_att_dst, d_bias
+  (exchange="x", chosen when F < Dp: all-gather the input rows instead and project them on
+  every rank; see _PartitionedFn)
 
 Blocks are equal (B = ceil(N / P) nodes, the last ones shorter or empty) so the
 collectives are the plain equal-shard forms.  The compute steps go through a small backend
@@ -137,40 +139,67 @@ class HipBackend:
         return ops.project_bwd(x, w, d_hp, cfg.heads, cfg.channels, need_dx)
 
 
+def _pad_rows(t: Tensor, rows: int) -> Tensor:
+    if t.size(0) == rows:
+        return t.contiguous()
+    out = t.new_zeros((rows,) + tuple(t.shape[1:]))
+    out[:t.size(0)] = t
+    return out
+
+
 class _PartitionedFn(torch.autograd.Function):
+    """exchange == "h": all-gather the projected features (Dp columns), reduce-scatter d_h.
+    exchange == "x": all-gather the INPUT rows (F columns) and project all of them on every
+    rank; the backward then needs no reduce-scatter of d_h -- d_W = sum_r d_h_r^T x is
+    finished by the parameter all-reduce, and only a layer whose input needs a gradient
+    reduce-scatters d_x (F columns).  Cheaper on the wire whenever F < Dp."""
+
     @staticmethod
-    def forward(ctx, x_local, weight, att_src, att_dst, bias, part, layout, cfg, be, group):
+    def forward(ctx, x_local, weight, att_src, att_dst, bias, part, layout, cfg, be, group,
+                exchange):
         x_local, weight = x_local.contiguous(), weight.contiguous()
         att_s, att_d = att_src.contiguous().view(-1), att_dst.contiguous().view(-1)
         bias_c = None if bias is None else bias.contiguous()
         f = x_local.size(1)
-        hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
-        shard = hp_local
-        if part.n_local < part.block:            # short / empty last block: pad to B rows
-            shard = hp_local.new_zeros(part.block, hp_local.size(1))
-            shard[:part.n_local] = hp_local
-        hp_full = all_gather_rows(shard, part.world, group)
+        if exchange == "x":
+            x_full = all_gather_rows(_pad_rows(x_local, part.block), part.world, group)
+            hp_full, a_dst_full = be.project_fwd(x_full, weight, att_d, cfg)
+            a_dst = a_dst_full[part.lo:part.hi].contiguous()
+            x_saved = x_full
+        else:
+            hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
+            hp_full = all_gather_rows(_pad_rows(hp_local, part.block), part.world, group)
+            x_saved = x_local
         need_grad = any(ctx.needs_input_grad[:5])
         out, lse = be.attn_fwd(layout, cfg, f, hp_full, a_dst, att_s, att_d, bias_c, need_grad)
         if need_grad:
-            ctx.save_for_backward(x_local, weight, att_s, att_d, bias_c, hp_full, a_dst, out, lse)
-            ctx.misc = (part, layout, cfg, be, group, att_src.shape)
+            ctx.save_for_backward(x_saved, weight, att_s, att_d, bias_c, hp_full, a_dst, out, lse)
+            ctx.misc = (part, layout, cfg, be, group, att_src.shape, exchange)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x_local, weight, att_s, att_d, bias_c, hp_full, a_dst, out, lse = ctx.saved_tensors
-        part, layout, cfg, be, group, att_shape = ctx.misc
+        x_saved, weight, att_s, att_d, bias_c, hp_full, a_dst, out, lse = ctx.saved_tensors
+        part, layout, cfg, be, group, att_shape, exchange = ctx.misc
+        need_dx = ctx.needs_input_grad[0]
         d_hp_part, d_as, d_ad, d_b, d_a_dst = be.attn_bwd(
-            layout, cfg, x_local.size(1), hp_full, a_dst, att_s, att_d, bias_c, out, lse,
+            layout, cfg, x_saved.size(1), hp_full, a_dst, att_s, att_d, bias_c, out, lse,
             grad_out.contiguous())
-        d_hp = reduce_scatter_rows(d_hp_part, part.world, part.rank, group)[:part.n_local]
-        d_hp = d_hp.contiguous()
-        be.add_dst_term(d_hp, d_a_dst, att_d, cfg)
-        d_w, d_x = be.project_bwd(x_local, weight, d_hp, cfg, ctx.needs_input_grad[0])
+        if exchange == "x":
+            own = d_hp_part[part.lo:part.hi]          # a view: the term lands in d_hp_part
+            be.add_dst_term(own, d_a_dst, att_d, cfg)
+            d_w, d_x_part = be.project_bwd(x_saved, weight, d_hp_part, cfg, need_dx)
+            d_x = None
+            if need_dx:
+                d_x = reduce_scatter_rows(d_x_part, part.world, part.rank, group)[:part.n_local]
+        else:
+            d_hp = reduce_scatter_rows(d_hp_part, part.world, part.rank, group)[:part.n_local]
+            d_hp = d_hp.contiguous()
+            be.add_dst_term(d_hp, d_a_dst, att_d, cfg)
+            d_w, d_x = be.project_bwd(x_saved, weight, d_hp, cfg, need_dx)
         all_reduce_many([d_w, d_as, d_ad, d_b], group)
         return (d_x, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class PartitionedGATConv(nn.Module):
@@ -179,7 +208,7 @@ class PartitionedGATConv(nn.Module):
     all-reduced, so every rank steps identically."""
 
     def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, dropout=0.0,
-                 bias=True, backend=None, group=None):
+                 bias=True, backend=None, group=None, exchange="auto"):
         super().__init__()
         from .layer import _glorot_
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
@@ -191,6 +220,9 @@ class PartitionedGATConv(nn.Module):
         _glorot_(self.lin.weight), _glorot_(self.att_src), _glorot_(self.att_dst)
         self.backend = backend or HipBackend()
         self.group = group
+        if exchange == "auto":     # fewer columns on the wire wins
+            exchange = "x" if in_channels < heads * ((out_channels + 3) // 4 * 4) else "h"
+        self.exchange = exchange
         self._layouts = {}
 
     def layout_for(self, edge_index: Tensor, part: Partition):
@@ -214,7 +246,8 @@ class PartitionedGATConv(nn.Module):
         cfg = AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
                          mask_mode, seed, None)
         return _PartitionedFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
-                                    self.bias, part, layout, cfg, self.backend, self.group)
+                                    self.bias, part, layout, cfg, self.backend, self.group,
+                                    self.exchange)
 
 
 # ------------------------------------------------------------------ bench.py --gpus N
@@ -228,7 +261,8 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     g = torch.Generator(device=dev).manual_seed(args.seed)
     x = torch.randn(n, f, generator=g, device=dev)[part.lo:part.hi].contiguous()
     torch.manual_seed(args.seed)
-    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout).to(dev).train()
+    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout,
+                              exchange=getattr(args, "exchange", "auto")).to(dev).train()
     torch.cuda.synchronize()
     t0 = time.time()
     layout = conv.layout_for(ei, part)
@@ -267,8 +301,11 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                                       f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
                                       f"layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
                           "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
-                          "parallelism": f"destination partition x{world}: all-gather(h) fwd, "
-                                         f"reduce-scatter(d_h) + all-reduce(param grads) bwd, RCCL",
+                          "parallelism": (f"destination partition x{world}, exchange={conv.exchange}: "
+                                          + ("all-gather(x) fwd, all-reduce(param grads) bwd"
+                                             if conv.exchange == "x" else
+                                             "all-gather(h) fwd, reduce-scatter(d_h) + all-reduce(param grads) bwd")
+                                          + ", RCCL"),
                           "graph_layout_build_s": round(t_layout, 4)},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(res))

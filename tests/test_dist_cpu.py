@@ -61,7 +61,7 @@ class OracleBackend:
         return d_hp.t() @ x, (d_hp @ w if need_dx else None)
 
 
-def _worker(rank, world, port, n, gname, q):
+def _worker(rank, world, port, n, gname, exchange, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -71,7 +71,7 @@ def _worker(rank, world, port, n, gname, q):
         f, h, c = 6, 3, 5
         x, w, a_s, a_d, b, go = [t.double() for t in cases.layer_inputs(n_, f, h, c)]
         part = Partition(n_, world, rank)
-        conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend()).double().eval()
+        conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend(), exchange=exchange).double().eval()
         with torch.no_grad():
             conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
         xl = x[part.lo:part.hi].clone().requires_grad_(True)
@@ -93,10 +93,10 @@ def _worker(rank, world, port, n, gname, q):
         dist.destroy_process_group()
 
 
-def _run(world, n, gname, port):
+def _run(world, n, gname, exchange, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gname, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gname, exchange, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -106,10 +106,11 @@ def _run(world, n, gname, port):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
-@pytest.mark.parametrize("world,n,gname,port", [(2, 50, None, 29611), (2, 51, None, 29612),
-                                                (2, None, "star", 29613), (3, 7, None, 29614)])
-def test_partitioned_layer_equals_single_process(world, n, gname, port):
-    _run(world, n, gname, port)
+@pytest.mark.parametrize("world,n,gname,exchange,port", [
+    (2, 50, None, "h", 29611), (2, 51, None, "x", 29612), (2, None, "star", "h", 29613),
+    (3, 7, None, "h", 29614), (2, None, "star", "x", 29615), (3, 7, None, "x", 29616)])
+def test_partitioned_layer_equals_single_process(world, n, gname, exchange, port):
+    _run(world, n, gname, exchange, port)
 
 
 def test_local_edges_keep_reference_order():
