@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgat_mi355.so")
+LIB_PATH = os.environ.get("GATMI_LIB") or os.path.join(_PKG, "libgat_mi355.so")  # override: kernel A/B builds
 
 MASK_NONE, MASK_BYTES, MASK_HASH = 0, 1, 2
 
@@ -62,7 +62,8 @@ SYMBOLS = {
     "gatmi_project_fwd": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_project_bwd": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "gatmi_attn_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_attn_fwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),

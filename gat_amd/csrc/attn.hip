@@ -4,6 +4,9 @@
 // reductions.  Stands for GATConv.forward/backward at /root/reference/gat/model.py:
 // 40,43,46,54.  HBM-bound: each kernel gathers every source
 // (or destination) feature row exactly once, one float4 per lane.
+#ifndef GATMI_U
+#define GATMI_U 4
+#endif
 #include "attn_device.h"
 #include "common.h"
 #include <stdlib.h>
@@ -76,7 +79,7 @@ struct RowArgs {
 // ---------------------------------------------------------------------------------
 template <int LPH2_T, int G, int T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
+    constexpr int U = (T == 1) ? GATMI_U : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
     float4 att[T], acc[T];
     float adi[T], m[T], ssum[T];
@@ -232,43 +235,115 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
 //   colsum    d_h[i] += d_a_dst[i] att_dst (row-local fix-up) fused with the parameter
 //             column sums.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_prep_kernel(
+// Fast form of bwd_prep_kernel for C % 4 == 0 with power-of-two lanes per head and slots per
+// row (compact == padded layout): the tables are streamed as flat float4 arrays, 4 in flight
+// per thread, the per-head dot is a shuffle butterfly -- no LDS, no barrier in the loop.
+__global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
     const float *gout, const float *outc, const float *bias, const float *a_dst, const float *lse,
-    long long total_groups, int H, int C, int Cp, float4 *nodeinfo, float *gp) {
-    __shared__ float part[256];
-    const int lph = Cp >> 2;
-    const int R = 256 / lph;
-    const long long g0 = (long long)blockIdx.x * R;
-    const int t = threadIdx.x, gl = t / lph, sub = t % lph;
-    const long long grp = g0 + gl;  // = node * H + head
-    float p = 0.f;
-    if (gl < R && grp < total_groups) {
-        const int head = (int)(grp % H);
-        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+    long long nq /* float4 count = N*Dp/4 */, int H, int lph_log, int nslot, float4 *nodeinfo,
+    float *gsum_partial) {
+    const int lph = 1 << lph_log;
+    const long long stride = (long long)gridDim.x * 256;   // multiple of nslot
+    const int slot = threadIdx.x & (nslot - 1);
+    const float4 b4 = bias ? ld4(bias + slot * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int UN = 4;
+    for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 - threadIdx.x % 64 < nq;
+         q0 += stride * UN) {
+        float4 g4[UN], o4[UN];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = sub * 4 + k;
-            if (c < C) {
-                const float g = gout[(size_t)grp * C + c];
-                const float o = outc[(size_t)grp * C + c] - (bias ? bias[head * C + c] : 0.f);
-                gv[k] = g;
-                p = fmaf(g, o, p);
+        for (int u = 0; u < UN; ++u) {
+            const long long q = q0 + u * stride;
+            const bool on = q < nq;
+            g4[u] = on ? ld4(gout + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o4[u] = on ? ld4(outc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long q = q0 + u * stride;
+            float4 o = o4[u];
+            o.x -= b4.x; o.y -= b4.y; o.z -= b4.z; o.w -= b4.w;
+            float p = dot4(g4[u], o);
+            for (int w = 1; w < lph; w <<= 1) p += __shfl_xor(p, w, 64);
+            gsum.x += g4[u].x; gsum.y += g4[u].y; gsum.z += g4[u].z; gsum.w += g4[u].w;
+            if (q < nq && (q & (lph - 1)) == 0) {
+                const long long grp = q >> lph_log;
+                nodeinfo[grp] = make_float4(a_dst[grp], lse[grp], p, 0.f);
             }
         }
-        if (gp) st4(gp + (size_t)grp * Cp + sub * 4, make_float4(gv[0], gv[1], gv[2], gv[3]));
     }
-    part[t] = p;
+    __shared__ float4 red[256];
+    red[threadIdx.x] = gsum;
     __syncthreads();
-    if (t < R && g0 + t < total_groups) {
-        float sd = 0.f;
-        for (int q = 0; q < lph; ++q) sd += part[t * lph + q];
-        nodeinfo[g0 + t] = make_float4(a_dst[g0 + t], lse[g0 + t], sd, 0.f);
+    if (threadIdx.x < nslot) {
+        float4 s4 = red[threadIdx.x];
+        for (int q = threadIdx.x + nslot; q < 256; q += nslot) {
+            const float4 o = red[q];
+            s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+        }
+        st4(gsum_partial + (size_t)blockIdx.x * nslot * 4 + slot * 4, s4);
+    }
+}
+
+__global__ __launch_bounds__(256) void bwd_prep_kernel(
+    const float *gout, const float *outc, const float *bias, const float *a_dst, const float *lse,
+    int N, int H, int C, int Cp, int Dp, float4 *nodeinfo, float *gp,
+    float *gsum_partial /* [blocks, Dp]: column sums of grad_out, for d_bias */) {
+    __shared__ float part[256];
+    const int nslot = Dp >> 2;
+    const int rows_per_pass = 256 / nslot;
+    const int slot = threadIdx.x % nslot, rsub = threadIdx.x / nslot;
+    const int lph = Cp >> 2;
+    const int head = slot / lph, sub = slot % lph;
+    const int coff = head * C + sub * 4;
+    int nval = C - sub * 4;
+    nval = nval > 4 ? 4 : nval;
+    const bool vec_ok = (C & 3) == 0;
+    const bool lane_ok = rsub < rows_per_pass;
+    const float4 b4 = (bias && lane_ok) ? ldc(bias + coff, nval, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long rows_per_block = ((long long)N + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min((long long)N, r0 + rows_per_block);
+    for (long long base = r0; base < r1; base += rows_per_pass) {
+        const long long r = base + rsub;
+        const bool on = lane_ok && r < r1;
+        float p = 0.f;
+        if (on) {
+            const float4 g4 = ldc(gout + r * H * C + coff, nval, vec_ok);
+            float4 o4 = ldc(outc + r * H * C + coff, nval, vec_ok);
+            o4.x -= b4.x; o4.y -= b4.y; o4.z -= b4.z; o4.w -= b4.w;
+            p = dot4(g4, o4);
+            gsum.x += g4.x; gsum.y += g4.y; gsum.z += g4.z; gsum.w += g4.w;
+            if (gp) st4(gp + r * Dp + slot * 4, g4);
+        }
+        part[threadIdx.x] = p;
+        __syncthreads();
+        if (on && sub == 0) {
+            float sd = 0.f;
+            for (int q = 0; q < lph; ++q) sd += part[threadIdx.x + q];
+            const long long grp = r * H + head;
+            nodeinfo[grp] = make_float4(a_dst[grp], lse[grp], sd, 0.f);
+        }
+        __syncthreads();
+    }
+    // block-level column sum of grad_out (fixed order over rsub)
+    __shared__ float4 red[256];
+    red[threadIdx.x] = gsum;
+    __syncthreads();
+    if (threadIdx.x < nslot) {
+        float4 s4 = red[threadIdx.x];
+        for (int q = 1; q < rows_per_pass; ++q) {
+            const float4 o = red[threadIdx.x + q * nslot];
+            s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+        }
+        st4(gsum_partial + (size_t)blockIdx.x * Dp + slot * 4, s4);
     }
 }
 
 template <int LPH2_T, int G, int T>
 __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? 4 : (T == 2 ? 2 : 1);
+    constexpr int U = (T == 1) ? GATMI_U : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
     float4 att[T], hj[T], acc[T];
     float asj[T], das[T];
@@ -428,18 +503,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dst_merge_kernel(
 constexpr int kColsumBlocks = 1024;
 
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(
-    const float *hp, const float *gp, const float *da_src, const float *da_dst,
-    const float *att_dst, float *dhp /* NULL: no fix-up */, int n_src, int n_dst, int dst_off,
-    int H, int C, int Cp, int Dp, float *partial /* [blocks, 3, Dp] */) {
-    __shared__ float4 red[3][256];
+    const float *hp, const float *da_src, const float *da_dst, const float *att_dst,
+    float *dhp /* NULL: no fix-up */, int n_src, int n_dst, int dst_off, int H, int C, int Cp,
+    int Dp, float *partial /* [blocks, 2, Dp] */) {
+    __shared__ float4 red[2][256];
     const int nslot = Dp >> 2;  // float4 slots per row, <= 256
     const int rows_per_pass = 256 / nslot;
     const int slot = threadIdx.x % nslot;
     const int rsub = threadIdx.x / nslot;
     const int head = (slot * 4) / Cp;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, g = a;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     float4 ad4 = a;  // att_dst of this slot (0 in the padding)
-    {
+    if (dhp) {
         const int c0 = slot * 4 - head * Cp;
         if (c0 + 0 < C) ad4.x = att_dst[head * C + c0 + 0];
         if (c0 + 1 < C) ad4.y = att_dst[head * C + c0 + 1];
@@ -451,13 +526,18 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
         const long long rows_per_block = (n_max + gridDim.x - 1) / gridDim.x;
         const long long r0 = (long long)blockIdx.x * rows_per_block;
         const long long r1 = min(n_max, r0 + rows_per_block);
+        const bool same = dst_off == 0;
+#pragma unroll 4
         for (long long r = r0 + rsub; r < r1; r += rows_per_pass) {
-            if (r < n_src) fma4(a, da_src[r * H + head], ld4(hp + r * Dp + slot * 4));
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < n_src) {
+                hv = ld4(hp + r * Dp + slot * 4);
+                fma4(a, da_src[r * H + head], hv);
+            }
             if (r < n_dst) {
                 const float dd = da_dst[r * H + head];
-                fma4(b, dd, ld4(hp + (r + dst_off) * Dp + slot * 4));
-                const float4 gv = ld4(gp + r * Dp + slot * 4);
-                g.x += gv.x; g.y += gv.y; g.z += gv.z; g.w += gv.w;
+                if (!same) hv = ld4(hp + (r + dst_off) * Dp + slot * 4);
+                fma4(b, dd, hv);
                 if (dhp) {  // d_h[r] += d_a_dst[r] att_dst
                     float4 dh = ld4(dhp + (r + dst_off) * Dp + slot * 4);
                     fma4(dh, dd, ad4);
@@ -468,16 +548,15 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
     }
     red[0][threadIdx.x] = a;
     red[1][threadIdx.x] = b;
-    red[2][threadIdx.x] = g;
     __syncthreads();
     if (threadIdx.x < nslot) {
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 2; ++k) {
             float4 s = red[k][threadIdx.x];
             for (int q = 1; q < rows_per_pass; ++q) {
                 const float4 o = red[k][threadIdx.x + q * nslot];
                 s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
             }
-            st4(partial + ((size_t)blockIdx.x * 3 + k) * Dp + slot * 4, s);
+            st4(partial + ((size_t)blockIdx.x * 2 + k) * Dp + slot * 4, s);
         }
     }
 }
@@ -504,18 +583,30 @@ __global__ __launch_bounds__(256) void add_dst_term_kernel(float *dh, const floa
     }
 }
 
+// One block per (term k, 64 padded columns): 4 row groups sum every 4th partial row, then a
+// fixed 4-way add -- reproducible, and parallel enough that it no longer shows in a profile.
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(
-    const float *partial, int nblocks, int H, int C, int Cp, int Dp, float *d_att_src,
-    float *d_att_dst, float *d_bias) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;  // over 3 * H * C
-    if (idx >= 3 * H * C) return;
-    const int k = idx / (H * C), hc = idx % (H * C);
-    const int pc = (hc / C) * Cp + hc % C;
+    const float *partial, int nblocks, const float *gsum_partial, int nblocks_g, int H, int C,
+    int Cp, int Dp, float *d_att_src, float *d_att_dst, float *d_bias) {
+    __shared__ float red[256];
+    const int k = blockIdx.y;
+    const int pc = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     float *dst = k == 0 ? d_att_src : (k == 1 ? d_att_dst : d_bias);
-    if (!dst) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 3 + k) * Dp + pc];
-    dst[hc] = s;
+    if (dst && pc < Dp) {
+        if (k < 2)
+            for (int b = rg; b < nblocks; b += 4) s += partial[((size_t)b * 2 + k) * Dp + pc];
+        else
+            for (int b = rg; b < nblocks_g; b += 4) s += gsum_partial[(size_t)b * Dp + pc];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && dst && pc < Dp) {
+        const float tot = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) +
+                          red[threadIdx.x + 192];
+        const int head = pc / Cp, c = pc % Cp;
+        if (c < C) dst[head * C + c] = tot;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -722,7 +813,7 @@ BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo,
     w.part_dad = cv.take<float>((size_t)g->plan.n_slots * H);
     w.part_das = cv.take<float>((size_t)g->plan_t.n_slots * H);
     w.part_dh = cv.take<float>((size_t)g->plan_t.n_slots * geo.Dp);
-    w.colsum = cv.take<float>((size_t)kColsumBlocks * 3 * geo.Dp);
+    w.colsum = cv.take<float>((size_t)kColsumBlocks * 3 * geo.Dp);  // [blocks,2,Dp] + [blocks,Dp]
     w.bytes = cv.off + 256;
     return w;
 }
@@ -753,15 +844,25 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     GATMI_REQUIRE(d_a_dst_out || N == NS,
                   "a destination partition must take d_a_dst (the d_h fix-up follows its reduce-scatter)");
     if (NS == 0) return GATMI_OK;
+    const int prep_blocks = N < kColsumBlocks ? (N > 0 ? N : 1) : kColsumBlocks;
+    float *gsum_partial = w.colsum + (size_t)kColsumBlocks * 2 * geo.Dp;
 
     {
         ProfScope ps("attn_bwd_prep", st);
-        const long long groups = (long long)N * H;
-        const int R = 256 / (geo.Cp / 4);
-        hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)((groups + R - 1) / R)), dim3(256), 0, st,
-                           grad_out, out, a->bias, a->a_dst, lse, groups, H, C, geo.Cp,
-                           reinterpret_cast<float4 *>(w.nodeinfo), w.gp);
-        GATMI_HIP(hipGetLastError());
+        const bool flat = (C & 3) == 0 && geo.lph == geo.lph2 && geo.lph <= 64 &&
+                          ((geo.Dp / 4) & (geo.Dp / 4 - 1)) == 0 && geo.Dp / 4 <= 256;
+        if (N > 0 && flat) {
+            hipLaunchKernelGGL(bwd_prep_flat_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out,
+                               out, a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H,
+                               geo.lph2_log, geo.Dp / 4, reinterpret_cast<float4 *>(w.nodeinfo),
+                               gsum_partial);
+            GATMI_HIP(hipGetLastError());
+        } else if (N > 0) {
+            hipLaunchKernelGGL(bwd_prep_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
+                               a->bias, a->a_dst, lse, N, H, C, geo.Cp, geo.Dp,
+                               reinterpret_cast<float4 *>(w.nodeinfo), w.gp, gsum_partial);
+            GATMI_HIP(hipGetLastError());
+        }
     }
     const float *gpad = w.gp ? w.gp : grad_out;
 
@@ -815,14 +916,14 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     {
         ProfScope ps("param_colsum", st);
         const int blocks = NS < kColsumBlocks ? NS : kColsumBlocks;
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, gpad,
-                           w.da_src, w.da_dst, a->att_dst, d_a_dst_out ? nullptr : d_hp, NS, N,
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, w.da_src,
+                           w.da_dst, a->att_dst, d_a_dst_out ? nullptr : d_hp, NS, N,
                            g->dst_offset, H, C, geo.Cp, geo.Dp, w.colsum);
         GATMI_HIP(hipGetLastError());
         if (d_att_src || d_att_dst || d_bias) {
-            const int tot = 3 * H * C;
-            hipLaunchKernelGGL(colsum_stage2_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
-                               w.colsum, blocks, H, C, geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
+            hipLaunchKernelGGL(colsum_stage2_kernel, dim3((geo.Dp + 63) / 64, 3), dim3(256), 0, st,
+                               w.colsum, blocks, gsum_partial, N > 0 ? prep_blocks : 0, H, C,
+                               geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
             GATMI_HIP(hipGetLastError());
         }
         if (d_a_dst_out)

@@ -17,11 +17,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
 
+// Optional correction of the A operand on its way into LDS (backward GEMMs only): A holds
+// d_h without the destination-logit term, the tile is staged as
+//   d_h[n, col] + d_a_dst[n, head(col)] * att_dst_p[col]
+// so that term never makes a round trip through HBM.
+struct AFix {
+    const float *da_dst;   // [rows, H], NULL = no correction
+    const float *att_p;    // [Dp] head-padded att_dst
+    int H, Cp;
+};
+
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ B, int ldb,
                                                        float *__restrict__ C, int ldc, int M,
-                                                       int Nn, int K, int k_per_split) {
+                                                       int Nn, int K, int k_per_split,
+                                                       const AFix fix) {
     __shared__ float As[BK][LDT];
     __shared__ float Bs[BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,8 +51,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        float ra[8], rb[8];
+    // Global -> registers for one K-tile (issued one tile ahead of its use), registers ->
+    // LDS, MFMA over the tile.
+    float ra[8], rb[8], rd[8];   // rd: d_a_dst of the element's node (AFix), applied at LDS-store
+    // time so the fetched tile stays in flight during the MFMA loop
+    // AFix, k-major A (d_weight): this thread's column m0 + tid % BM never changes
+    int fix_head = 0;
+    float fix_att = 0.f, fix_att_tile = 0.f;
+    if (A_KMAJOR && fix.da_dst && m0 + tid % BM < M) {
+        fix_head = (int)(m0 + tid % BM) / fix.Cp;
+        fix_att = fix.att_p[m0 + tid % BM];
+    }
+    auto fetch = [&](int k0) {
+        if (!A_KMAJOR && fix.da_dst) {   // row-major A (d_x): column k0 + tid % BK, once per tile
+            const int col = k0 + tid % BK;
+            fix_head = col / fix.Cp;
+            fix_att = col < kend ? fix.att_p[col] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256;
@@ -51,6 +77,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             const int gk = k0 + k;
             const bool ok = gm < M && gk < kend;
             ra[i] = ok ? (A_KMAJOR ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
+            if (fix.da_dst) {
+                const long long node = A_KMAJOR ? gk : gm;   // row of the d_h table
+                rd[i] = ok ? fix.da_dst[node * fix.H + fix_head] : 0.f;
+            }
             int n;
             if (B_KMAJOR) { n = idx % BN; k = idx / BN; } else { k = idx % BK; n = idx / BK; }
             const int gn = n0 + n;
@@ -58,18 +88,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             const bool okb = gn < Nn && gk2 < kend;
             rb[i] = okb ? (B_KMAJOR ? B[(size_t)gk2 * ldb + gn] : B[(size_t)gn * ldb + gk2]) : 0.f;
         }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        fix_att_tile = fix_att;   // att of the tile now in registers (fetch() overwrites fix_att)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256;
             int m, k;
             if (A_KMAJOR) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
-            As[k][m] = ra[i];
+            As[k][m] = fix.da_dst ? fmaf(rd[i], fix_att_tile, ra[i]) : ra[i];
             int n;
             if (B_KMAJOR) { n = idx % BN; k = idx / BN; } else { k = idx % BK; n = idx / BK; }
             Bs[k][n] = rb[i];
         }
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);   // in flight while this tile is multiplied
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + (lane >> 5);
@@ -159,20 +194,50 @@ __global__ __launch_bounds__(256) void row_dots_kernel(const float *hp, const fl
     }
 }
 
+// row_dots for power-of-two lanes per head: flat float4 stream, shuffle butterfly.
+__global__ __launch_bounds__(256) void row_dots_flat_kernel(const float *hp, const float *att_p,
+                                                            float *a_dst, long long nq, int H,
+                                                            int lph_log, int Cp) {
+    const int lph = 1 << lph_log;
+    const long long stride = (long long)gridDim.x * 256;
+    constexpr int UN = 4;
+    for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 - threadIdx.x % 64 < nq;
+         q0 += stride * UN) {
+        float4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long q = q0 + u * stride;
+            v[u] = q < nq ? *reinterpret_cast<const float4 *>(hp + q * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long q = q0 + u * stride;
+            const long long grp = q >> lph_log;
+            const int head = (int)(grp % H), sub = (int)(q & (lph - 1));
+            const float4 a4 = *reinterpret_cast<const float4 *>(att_p + head * Cp + sub * 4);
+            float p = fmaf(v[u].w, a4.w, fmaf(v[u].z, a4.z, fmaf(v[u].y, a4.y, v[u].x * a4.x)));
+            for (int w = 1; w < lph; w <<= 1) p += __shfl_xor(p, w, 64);
+            if (q < nq && sub == 0) a_dst[grp] = p;
+        }
+    }
+}
+
 static int launch_gemm(bool a_km, bool b_km, const float *A, int lda, const float *B, int ldb,
-                       float *C, int ldc, int M, int Nn, int K, int nsplit, hipStream_t st) {
+                       float *C, int ldc, int M, int Nn, int K, int nsplit, hipStream_t st,
+                       AFix fix = AFix{nullptr, nullptr, 1, 1}) {
     if (M == 0 || Nn == 0) return GATMI_OK;
     const int kps = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
     dim3 grid((M + BM - 1) / BM, (Nn + BN - 1) / BN, nsplit);
     if (!a_km && !b_km)
         hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, A, lda, B, ldb,
-                           C, ldc, M, Nn, K, kps);
+                           C, ldc, M, Nn, K, kps, fix);
     else if (!a_km && b_km)
         hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb,
-                           C, ldc, M, Nn, K, kps);
+                           C, ldc, M, Nn, K, kps, fix);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, A, lda, B, ldb,
-                           C, ldc, M, Nn, K, kps);
+                           C, ldc, M, Nn, K, kps, fix);
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
@@ -194,7 +259,7 @@ extern "C" size_t gatmi_project_workspace_bytes(const gatmi_shape *s) {
     const size_t Cp = round_up4(s->channels), Dp = Cp * s->heads, F = s->in_features;
     const size_t wp = align_up(Dp * F * 4);
     const size_t slab = align_up((size_t)dweight_splits(s->num_nodes, (int)Dp, (int)F) * Dp * F * 4);
-    return wp + slab + 256;
+    return wp + slab + align_up(Dp * 4) + 256;
 }
 
 static const float *padded_weight(const gatmi_shape *s, const float *weight, float *wp_buf,
@@ -233,18 +298,32 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
     if (a_dst) {
         ProfScope ps("proj_row_dots", st);
         GATMI_REQUIRE(att_dst, "a_dst requested without att_dst");
-        const int R = 256 / (Cp / 4);
+        const int lph = Cp / 4;
         const long long groups = (long long)N * H;
-        hipLaunchKernelGGL(row_dots_kernel, dim3((unsigned)((groups + R - 1) / R)), dim3(256), 0,
-                           st, hp, att_dst, a_dst, groups, H, C, Cp);
+        if ((lph & (lph - 1)) == 0 && lph <= 64) {
+            // padded att_dst behind the padded weight in the workspace
+            float *att_p = reinterpret_cast<float *>(static_cast<char *>(ws) +
+                                                     align_up((size_t)Dp * F * 4));
+            hipLaunchKernelGGL(pad_weight_kernel, dim3(1), dim3(256), 0, st, att_dst, att_p, H, C,
+                               Cp, 1);
+            const long long nq = groups * lph;
+            const long long want = (nq + 256 * 4 - 1) / (256 * 4);
+            hipLaunchKernelGGL(row_dots_flat_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)),
+                               dim3(256), 0, st, hp, att_p, a_dst, nq, H, ilog2(lph), Cp);
+        } else {
+            const int R = 256 / lph;
+            hipLaunchKernelGGL(row_dots_kernel, dim3((unsigned)((groups + R - 1) / R)), dim3(256),
+                               0, st, hp, att_dst, a_dst, groups, H, C, Cp);
+        }
         GATMI_HIP(hipGetLastError());
     }
     return GATMI_OK;
 }
 
 extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const float *weight,
-                                 const float *d_hp, float *d_weight, float *d_x, void *ws,
-                                 size_t ws_bytes, void *stream) {
+                                 const float *d_hp, const float *d_a_dst, const float *att_dst,
+                                 float *d_weight, float *d_x, void *ws, size_t ws_bytes,
+                                 void *stream) {
     GATMI_REQUIRE(s && x && weight && d_hp, "null argument");
     if (ws_bytes < gatmi_project_workspace_bytes(s)) {
         set_error("project workspace too small: %zu < %zu", ws_bytes,
@@ -256,13 +335,23 @@ extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const flo
     const int Cp = round_up4(C), Dp = H * Cp;
     float *wp_buf = static_cast<float *>(ws);
     float *slab = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)Dp * F * 4));
+    AFix fix{nullptr, nullptr, H, Cp};
+    if (d_a_dst) {
+        GATMI_REQUIRE(att_dst, "d_a_dst given without att_dst");
+        float *att_p = reinterpret_cast<float *>(reinterpret_cast<char *>(slab) +
+                                                 align_up((size_t)dweight_splits(N, Dp, F) * Dp * F * 4));
+        hipLaunchKernelGGL(pad_weight_kernel, dim3(1), dim3(256), 0, st, att_dst, att_p, H, C, Cp, 1);
+        GATMI_HIP(hipGetLastError());
+        fix.da_dst = d_a_dst;
+        fix.att_p = att_p;
+    }
     if (d_weight) {
         if (N == 0) {
             GATMI_HIP(hipMemsetAsync(d_weight, 0, (size_t)H * C * F * 4, st));
         } else {
             ProfScope ps("proj_bwd_w_gemm", st);
             const int ns = dweight_splits(N, Dp, F);
-            if (int e = launch_gemm(true, true, d_hp, Dp, x, F, slab, F, Dp, F, N, ns, st)) return e;
+            if (int e = launch_gemm(true, true, d_hp, Dp, x, F, slab, F, Dp, F, N, ns, st, fix)) return e;
             const long long tot = (long long)H * C * F;
             const int blocks = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
             hipLaunchKernelGGL(reduce_dweight_kernel, dim3(blocks), dim3(256), 0, st, slab, ns, H,
@@ -274,7 +363,7 @@ extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const flo
         const float *wp = padded_weight(s, weight, wp_buf, st);
         GATMI_HIP(hipGetLastError());
         ProfScope ps("proj_bwd_x_gemm", st);
-        if (int e = launch_gemm(false, true, d_hp, Dp, wp, F, d_x, F, N, F, Dp, 1, st)) return e;
+        if (int e = launch_gemm(false, true, d_hp, Dp, wp, F, d_x, F, N, F, Dp, 1, st, fix)) return e;
     }
     return GATMI_OK;
 }

@@ -136,7 +136,7 @@ class HipBackend:
 
     def project_bwd(self, x, w, d_hp, cfg, need_dx):
         from . import ops
-        return ops.project_bwd(x, w, d_hp, cfg.heads, cfg.channels, need_dx)
+        return ops.project_bwd(x, w, d_hp.contiguous(), cfg.heads, cfg.channels, need_dx)
 
 
 def _pad_rows(t: Tensor, rows: int) -> Tensor:

@@ -40,10 +40,11 @@ class _GATConvFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         x, weight, att_s, att_d, bias_c, hp, a_dst, out, lse = ctx.saved_tensors
         cfg, layout = ctx.cfg, ctx.layout
-        d_hp, d_as, d_ad, d_b, _ = ops.attn_bwd(layout, cfg, x.size(1), hp, a_dst, att_s, att_d,
-                                                bias_c, out, lse, grad_out.contiguous())
+        d_hp, d_as, d_ad, d_b, d_a_dst = ops.attn_bwd(
+            layout, cfg, x.size(1), hp, a_dst, att_s, att_d, bias_c, out, lse,
+            grad_out.contiguous(), defer_dst_term=True)
         d_w, d_x = ops.project_bwd(x, weight, d_hp, cfg.heads, cfg.channels,
-                                   ctx.needs_input_grad[0])
+                                   ctx.needs_input_grad[0], d_a_dst, att_d)
         return d_x, d_w, d_as.view(ctx.att_shape), d_ad.view(ctx.att_shape), d_b, None, None
 
 

@@ -65,7 +65,10 @@ def project_fwd(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels
 
 
 def project_bwd(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channels: int,
-                need_dx: bool) -> Tuple[Tensor, Optional[Tensor]]:
+                need_dx: bool, d_a_dst: Optional[Tensor] = None, att_dst: Optional[Tensor] = None
+                ) -> Tuple[Tensor, Optional[Tensor]]:
+    """d_weight, d_x.  With d_a_dst/att_dst the term d_a_dst * att_dst still missing from
+    d_hp is added while its tiles are staged (see gatmi_project_bwd)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
     shape = _lib.Shape(n, f, heads, channels)
@@ -74,8 +77,9 @@ def project_bwd(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channels: i
         d_x = torch.empty_like(x) if need_dx else None
         ws = _ws(lib.gatmi_project_workspace_bytes(C.byref(shape)), dev)
         _lib.check(lib.gatmi_project_bwd(C.byref(shape), x.data_ptr(), weight.data_ptr(),
-                                         d_hp.data_ptr(), d_w.data_ptr(), _ptr(d_x),
-                                         ws.data_ptr(), ws.numel(), _stream(dev)), "gatmi_project_bwd")
+                                         d_hp.data_ptr(), _ptr(d_a_dst), _ptr(att_dst),
+                                         d_w.data_ptr(), _ptr(d_x), ws.data_ptr(), ws.numel(),
+                                         _stream(dev)), "gatmi_project_bwd")
     return d_w, d_x
 
 

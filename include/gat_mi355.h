@@ -128,10 +128,13 @@ int gatmi_project_fwd(const gatmi_shape *s, const float *x, const float *weight,
                       void *ws, size_t ws_bytes, void *stream);
 
 /* Backward of the projection (row a11, last two formulae): d_weight = d_hp^T x,
- * d_x = d_hp W (skipped when d_x == NULL).   d_hp [N,Dp] -> d_weight [H*C,F], d_x [N,F] */
+ * d_x = d_hp W (skipped when d_x == NULL).   d_hp [N,Dp] -> d_weight [H*C,F], d_x [N,F]
+ * d_a_dst != NULL ([N,H], with att_dst [H*C]): d_hp is what gatmi_attn_bwd leaves when it
+ * hands out d_a_dst, and the missing term d_a_dst[n,h] * att_dst[h,:] is added while the
+ * d_hp tiles are staged for the two GEMMs (it never goes through HBM). */
 int gatmi_project_bwd(const gatmi_shape *s, const float *x, const float *weight,
-                      const float *d_hp, float *d_weight, float *d_x,
-                      void *ws, size_t ws_bytes, void *stream);
+                      const float *d_hp, const float *d_a_dst, const float *att_dst,
+                      float *d_weight, float *d_x, void *ws, size_t ws_bytes, void *stream);
 
 /* Arguments of the fused attention kernels. */
 typedef struct gatmi_attn {
@@ -170,8 +173,9 @@ int gatmi_dropout_mask(const gatmi_graph *g, int heads, float dropout_p, uint64_
  *   -> d_hp [num_src, Dp], d_att_src [H*C], d_att_dst [H*C], d_bias [H*C] (NULL to skip)
  * d_a_dst_out == NULL (square graphs only): d_hp is complete on return.
  * d_a_dst_out != NULL: [num_dst, H] receives d a_dst and d_hp lacks the term
- * d_a_dst[i] * att_dst of its destination rows -- a destination partition adds it with
- * gatmi_add_dst_term after the reduce-scatter of d_hp. */
+ * d_a_dst[i] * att_dst of its destination rows: gatmi_project_bwd adds it on the fly
+ * (saves a read-modify-write of d_hp); a destination partition adds it after the
+ * reduce-scatter of d_hp, there or with gatmi_add_dst_term. */
 size_t gatmi_attn_bwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
 int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
                    const float *lse, const float *grad_out, float *d_hp,

@@ -114,10 +114,19 @@ def test_projection_fwd_bwd(cuda, n, f, h, c):
     dw = torch.empty(h * c, f, device=cuda)
     dx = torch.empty(n, f, device=cuda)
     _lib.check(lib.gatmi_project_bwd(C.byref(shape), xd.data_ptr(), wd.data_ptr(), dhd.data_ptr(),
-                                     dw.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd")
+                                     None, None, dw.data_ptr(), dx.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), st), "bwd")
     dhc = dh[:, :, :c].reshape(n, h * c).double()
     close(dw, (dhc.t() @ x.double()).float(), "d_weight")
     close(dx, (dhc @ w.double()).float(), "d_x")
+    # with the destination-logit term added while the tiles are staged
+    da = torch.randn(n, h, generator=g)
+    _lib.check(lib.gatmi_project_bwd(C.byref(shape), xd.data_ptr(), wd.data_ptr(), dhd.data_ptr(),
+                                     da.to(cuda).data_ptr(), ad.data_ptr(), dw.data_ptr(),
+                                     dx.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd+term")
+    full = (dh[:, :, :c].double() + da.double().unsqueeze(-1) * att.double().view(1, h, c)).reshape(n, h * c)
+    close(dw, (full.t() @ x.double()).float(), "d_weight+term")
+    close(dx, (full @ w.double()).float(), "d_x+term")
 
 
 # ------------------------------------------------------------------ whole layer
