@@ -34,6 +34,18 @@ def kernel_bytes(n, e, h, d):
     }
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot
+    collect counters itself); None when no measurement exists for this workload/kernel."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t["kernels"].get(kernel) if t.get("workload") == workload else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(name, seed, budget_s=25.0):
     """The oracle (CPU restatement of the reference's path) timed on this host's cores on
     a bounded sample of the same workload: the same generator at reduced scale."""
@@ -144,7 +156,8 @@ def main():
     dom = max(kb, key=lambda k: avg.get(k, 0.0))
     achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic(args.workload, dom),
                 "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom]}
     kernels = {k: {"avg_ms": round(v, 4),
                    **({"alg_GBps": round(kb[k] / (v * 1e-3) / 1e9, 1)} if k in kb else {})}
