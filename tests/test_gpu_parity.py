@@ -369,3 +369,38 @@ def test_partition_kernels_match_oracle(cuda, gname, sname, world):
     close(d_as, ref_g["att_src"], "d_att_src", floor=summand)
     close(d_ad, ref_g["att_dst"], "d_att_dst", floor=summand)
     close(d_b, ref_g["bias"], "d_bias")
+
+
+# ------------------------------------------------------------------ randomized sweep
+def test_random_shapes_and_graphs(cuda):
+    """40 seeded random (graph, shape, dropout, seg_len) draws, including heads that are not a
+    power of two, channels 1..70, empty rows, duplicate edges and self-loops."""
+    import random
+    rng = random.Random(1234)
+    for trial in range(40):
+        n = rng.choice([1, 2, 3, 17, 64, 65, 200, 333])
+        e = rng.choice([0, 1, n, 5 * n, 20 * n])
+        h = rng.choice([1, 2, 3, 4, 5, 8])
+        c = rng.choice([1, 2, 3, 4, 7, 8, 16, 30, 33, 64, 70])
+        if h * ((c + 3) // 4 * 4) > 1024:
+            continue
+        f = rng.choice([1, 3, 16, 25, 100])
+        p = rng.choice([0.0, 0.0, 0.3, 0.6])
+        seg = rng.choice([64, 128, 512])
+        g = torch.Generator().manual_seed(trial)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        if e > 4:
+            ei[1, : e // 3] = ei[1, 0]            # a hub destination
+            ei[0, e // 3: e // 2] = ei[0, -1]      # a hub source
+        inputs = cases.layer_inputs(n, f, h, c, seed=trial)
+        x, w, a_s, a_d, b, go = inputs
+        ne = O.build_csr(ei, n).num_edges
+        mask = cases.keep_mask(ne, h, p, seed=trial) if p > 0 else None
+        ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                                  mask=mask, training=p > 0)
+        out, gr = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs)
+        tag = f"trial {trial}: n={n} e={e} h={h} c={c} f={f} p={p} seg={seg}"
+        close(out, ref_out, tag + " out")
+        summand = float(go.abs().max() * (x @ w.t()).abs().max())
+        for k in ref_g:
+            close(gr[k], ref_g[k], f"{tag} d_{k}", floor=summand if k.startswith("att") else 0.0)
