@@ -583,27 +583,34 @@ __global__ __launch_bounds__(256) void add_dst_term_kernel(float *dh, const floa
     }
 }
 
-// One block per (term k, 64 padded columns): 4 row groups sum every 4th partial row, then a
-// fixed 4-way add -- reproducible, and parallel enough that it no longer shows in a profile.
+// One block per (term k, 16 padded columns): 16 row groups each sum every 16th partial row
+// (4 loads in flight), then a fixed-order 16-way add -- reproducible and short.
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(
     const float *partial, int nblocks, const float *gsum_partial, int nblocks_g, int H, int C,
     int Cp, int Dp, float *d_att_src, float *d_att_dst, float *d_bias) {
     __shared__ float red[256];
     const int k = blockIdx.y;
-    const int pc = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int pc = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
     float *dst = k == 0 ? d_att_src : (k == 1 ? d_att_dst : d_bias);
-    float s = 0.f;
+    const float *src = k < 2 ? partial + (size_t)k * Dp : gsum_partial;
+    const size_t ld = k < 2 ? (size_t)2 * Dp : (size_t)Dp;
+    const int nb = k < 2 ? nblocks : nblocks_g;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (dst && pc < Dp) {
-        if (k < 2)
-            for (int b = rg; b < nblocks; b += 4) s += partial[((size_t)b * 2 + k) * Dp + pc];
-        else
-            for (int b = rg; b < nblocks_g; b += 4) s += gsum_partial[(size_t)b * Dp + pc];
+        int b = rg;
+        for (; b + 48 < nb; b += 64) {
+            s0 += src[(size_t)b * ld + pc];
+            s1 += src[(size_t)(b + 16) * ld + pc];
+            s2 += src[(size_t)(b + 32) * ld + pc];
+            s3 += src[(size_t)(b + 48) * ld + pc];
+        }
+        for (; b < nb; b += 16) s0 += src[(size_t)b * ld + pc];
     }
-    red[threadIdx.x] = s;
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && dst && pc < Dp) {
-        const float tot = ((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) +
-                          red[threadIdx.x + 192];
+        float tot = 0.f;
+        for (int q = 0; q < 16; ++q) tot += red[threadIdx.x + q * 16];
         const int head = pc / Cp, c = pc % Cp;
         if (c < C) dst[head * C + c] = tot;
     }
@@ -665,13 +672,27 @@ static int launch_rows(Kind k, const Geometry &g, const RowArgs &A, hipStream_t 
             launch_kind<0, 64, 4>(k, A, grid, st);
         }
     } else {
-        switch (g.G) {
-            case 32: launch_kind<0, 32, 1>(k, A, grid, st); break;
-            case 16: launch_kind<0, 16, 1>(k, A, grid, st); break;
-            case 8: launch_kind<0, 8, 1>(k, A, grid, st); break;
-            case 4: launch_kind<0, 4, 1>(k, A, grid, st); break;
-            case 2: launch_kind<0, 2, 1>(k, A, grid, st); break;
-            default: launch_kind<0, 1, 1>(k, A, grid, st); break;
+        // common narrow layers get the DPP butterfly at compile time: one head (G == lanes
+        // per head), and 8 heads of <= 8 channels (Cora-shaped layer 1)
+        const int key = g.G * 100 + g.lph2;
+        switch (key) {
+            case 1616: launch_kind<16, 16, 1>(k, A, grid, st); break;
+            case 808: launch_kind<8, 8, 1>(k, A, grid, st); break;
+            case 404: launch_kind<4, 4, 1>(k, A, grid, st); break;
+            case 202: launch_kind<2, 2, 1>(k, A, grid, st); break;
+            case 1602: launch_kind<2, 16, 1>(k, A, grid, st); break;
+            case 3204: launch_kind<4, 32, 1>(k, A, grid, st); break;
+            case 101: launch_kind<1, 1, 1>(k, A, grid, st); break;
+            case 801: launch_kind<1, 8, 1>(k, A, grid, st); break;
+            default:
+                switch (g.G) {
+                    case 32: launch_kind<0, 32, 1>(k, A, grid, st); break;
+                    case 16: launch_kind<0, 16, 1>(k, A, grid, st); break;
+                    case 8: launch_kind<0, 8, 1>(k, A, grid, st); break;
+                    case 4: launch_kind<0, 4, 1>(k, A, grid, st); break;
+                    case 2: launch_kind<0, 2, 1>(k, A, grid, st); break;
+                    default: launch_kind<0, 1, 1>(k, A, grid, st); break;
+                }
         }
     }
     GATMI_HIP(hipGetLastError());
@@ -921,7 +942,7 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
                            g->dst_offset, H, C, geo.Cp, geo.Dp, w.colsum);
         GATMI_HIP(hipGetLastError());
         if (d_att_src || d_att_dst || d_bias) {
-            hipLaunchKernelGGL(colsum_stage2_kernel, dim3((geo.Dp + 63) / 64, 3), dim3(256), 0, st,
+            hipLaunchKernelGGL(colsum_stage2_kernel, dim3((geo.Dp + 15) / 16, 3), dim3(256), 0, st,
                                w.colsum, blocks, gsum_partial, N > 0 ? prep_blocks : 0, H, C,
                                geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
             GATMI_HIP(hipGetLastError());
