@@ -22,15 +22,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def kernel_bytes(n, e, h, d):
+def kernel_bytes(n, e, h, d, f):
     """Algorithmic bytes per launch of the two heavy edge kernels (fp32 values, int32
     indices).  Forward is SURVEY.md 8d's B_fwd.  The backward gathers
     features once instead of SURVEY 8d's twice: one pass over the transposed CSR reads, per
     edge, the grad_out row (4D), the destination's 16H-byte record, col_t and pos_t, and
     writes d_u (4H); per node it reads h, writes d_h and d_a_src."""
+    fp = (f + 3) // 4 * 4
     return {
         "attn_fwd": e * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
         "attn_bwd_edge": e * (4 * d + 16 * h + 8 + 4 * h) + n * (8 * d + 4 * h),
+        # input-side aggregation (gat_amd/csrc/inagg.hip): an edge moves an x row (4 Fp) and its
+        # col index; a node reads rowptr and its own x row, writes Z [H, Fp] and lse (forward),
+        # reads q, Z [H, Fp] and lse (backward; nothing is written per edge or per node)
+        "inagg_fwd": e * (4 * fp + 4) + n * (4 + 4 * fp + 4 * h * fp + 4 * h),
+        "inagg_bwd_edge": e * (4 * fp + 4) + n * (4 + 4 * fp + 8 * h * fp + 4 * h),
     }
 
 
@@ -152,7 +158,7 @@ def main():
     for tag, ms in recs:
         per.setdefault(tag, []).append(ms)
     avg = {k: sum(v) / len(v) for k, v in per.items()}
-    kb = kernel_bytes(n, ep, h, d)
+    kb = kernel_bytes(n, ep, h, d, f)
     dom = max(kb, key=lambda k: avg.get(k, 0.0))
     achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -74,4 +74,32 @@ inline int item_grid(long long n_groups_needed, int groups_per_block) {
     return (int)((blocks + 7) / 8 * 8);
 }
 
+// ---- fp32 MFMA GEMM of project.hip, shared with the input-side aggregation path ----
+// Optional correction of the A operand on its way into LDS (backward GEMMs only): A holds
+// d_h without the destination-logit term, the tile is staged as
+//   d_h[n, col] + d_a_dst[n, head(col)] * att_dst_p[col]
+// so that term never makes a round trip through HBM.
+struct AFix {
+    const float *da_dst;   // [rows, H], NULL = no correction
+    const float *att_p;    // [Dp] head-padded att_dst
+    int H, Cp;
+};
+struct GemmBatch {
+    long long sA, sB, sC, sSplit, sBias;
+    const float *bias;
+    int nsplit, n_store;
+};
+// C[batch][split] (M x n_store, row stride ldc) = A (M x K) * B (K x Nn) over this split's K range.
+//   a_kmajor: A[k * lda + m] else A[m * lda + k];   b_kmajor: B[k * ldb + n] else B[n * ldb + k]
+struct GemmDesc {
+    bool a_kmajor, b_kmajor;
+    const float *A; int lda; long long sA;
+    const float *B; int ldb; long long sB;
+    float *C; int ldc; long long sC, sSplit;
+    int M, Nn, K, n_store, nbatch, nsplit;
+    const float *bias; long long sBias;
+    AFix fix;
+};
+int launch_gemm(const GemmDesc &d, hipStream_t st);
+
 }  // namespace gatmi

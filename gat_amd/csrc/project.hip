@@ -15,45 +15,48 @@ namespace gatmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+constexpr int BK = 16;
 
-// Optional correction of the A operand on its way into LDS (backward GEMMs only): A holds
-// d_h without the destination-logit term, the tile is staged as
-//   d_h[n, col] + d_a_dst[n, head(col)] * att_dst_p[col]
-// so that term never makes a round trip through HBM.
-struct AFix {
-    const float *da_dst;   // [rows, H], NULL = no correction
-    const float *att_p;    // [Dp] head-padded att_dst
-    int H, Cp;
-};
+// AFix, GemmBatch, GemmDesc: common.h
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// Tile BM x BN (64 or 128 each), 4 waves as 2 x 2, each wave (BM/64) x (BN/64) MFMA tiles of
+// 32 x 32.  blockIdx.z = batch * nsplit + split: `batch` walks independent products (one per
+// attention head: pointer strides sA/sB/sC), `split` cuts K (partial results sSplit apart).
+// Columns [Nn, n_store) of C are written as zeros (padding of a head-padded row); bias, when
+// given, is added per column.
+template <bool A_KMAJOR, bool B_KMAJOR, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ B, int ldb,
                                                        float *__restrict__ C, int ldc, int M,
                                                        int Nn, int K, int k_per_split,
-                                                       const AFix fix) {
-    __shared__ float As[BK][LDT];
-    __shared__ float Bs[BK][LDT];
+                                                       const AFix fix, const GemmBatch gb) {
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;   // staged elements per thread
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Bs[BK][BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * k_per_split;
+    const int split = blockIdx.z % gb.nsplit, batch = blockIdx.z / gb.nsplit;
+    const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
-    C += (size_t)blockIdx.z * (size_t)M * ldc;
+    A += (size_t)batch * gb.sA;
+    B += (size_t)batch * gb.sB;
+    C += (size_t)batch * gb.sC + (size_t)split * gb.sSplit;
+    const float *bias = gb.bias ? gb.bias + (size_t)batch * gb.sBias : nullptr;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // Global -> registers for one K-tile (issued one tile ahead of its use), registers ->
     // LDS, MFMA over the tile.
-    float ra[8], rb[8], rd[8];   // rd: d_a_dst of the element's node (AFix), applied at LDS-store
+    float ra[EA], rb[EB], rd[EA];   // rd: d_a_dst of the element's node (AFix), applied at LDS-store
     // time so the fetched tile stays in flight during the MFMA loop
     // AFix, k-major A (d_weight): this thread's column m0 + tid % BM never changes
     int fix_head = 0;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             fix_att = col < kend ? fix.att_p[col] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < EA; ++i) {
             const int idx = tid + i * 256;
             int m, k;
             if (A_KMAJOR) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
@@ -81,7 +84,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                 const long long node = A_KMAJOR ? gk : gm;   // row of the d_h table
                 rd[i] = ok ? fix.da_dst[node * fix.H + fix_head] : 0.f;
             }
-            int n;
+        }
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
+            const int idx = tid + i * 256;
+            int n, k;
             if (B_KMAJOR) { n = idx % BN; k = idx / BN; } else { k = idx % BK; n = idx / BK; }
             const int gn = n0 + n;
             const int gk2 = k0 + k;
@@ -94,12 +101,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
         fix_att_tile = fix_att;   // att of the tile now in registers (fetch() overwrites fix_att)
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < EA; ++i) {
             const int idx = tid + i * 256;
             int m, k;
             if (A_KMAJOR) { m = idx % BM; k = idx / BM; } else { k = idx % BK; m = idx / BK; }
             As[k][m] = fix.da_dst ? fmaf(rd[i], fix_att_tile, ra[i]) : ra[i];
-            int n;
+        }
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
+            const int idx = tid + i * 256;
+            int n, k;
             if (B_KMAJOR) { n = idx % BN; k = idx / BN; } else { k = idx % BK; n = idx / BK; }
             Bs[k][n] = rb[i];
         }
@@ -108,28 +119,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + (lane >> 5);
-            float a[2], b[2];
+            float a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[kr][wm * 64 + i * 32 + (lane & 31)];
+            for (int i = 0; i < MI; ++i) a[i] = As[kr][wm * (BM / 2) + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn * 64 + j * 32 + (lane & 31)];
+            for (int j = 0; j < NJ; ++j) b[j] = Bs[kr][wn * (BN / 2) + j * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cn = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int cn = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            const float bv = (bias && cn < Nn) ? bias[cn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long cm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (cm < M && cn < Nn) C[(size_t)cm * ldc + cn] = acc[i][j][r];
+                const long long cm =
+                    m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cm < M && cn < gb.n_store) C[(size_t)cm * ldc + cn] = acc[i][j][r] + bv;
             }
         }
 }
@@ -230,27 +243,58 @@ __global__ __launch_bounds__(256) void row_dots_flat_kernel(const float *hp, con
     }
 }
 
-static int launch_gemm(bool a_km, bool b_km, const float *A, int lda, const float *B, int ldb,
-                       float *C, int ldc, int M, int Nn, int K, int nsplit, hipStream_t st,
-                       AFix fix = AFix{nullptr, nullptr, 1, 1}) {
-    if (M == 0 || Nn == 0) return GATMI_OK;
-    const int kps = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-    dim3 grid((M + BM - 1) / BM, (Nn + BN - 1) / BN, nsplit);
-    if (!a_km && !b_km)
-        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, A, lda, B, ldb,
-                           C, ldc, M, Nn, K, kps, fix);
-    else if (!a_km && b_km)
-        hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb,
-                           C, ldc, M, Nn, K, kps, fix);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, A, lda, B, ldb,
-                           C, ldc, M, Nn, K, kps, fix);
+template <bool AK, bool BK_, int BM, int BN>
+static void launch_tile(const GemmDesc &d, int kps, hipStream_t st) {
+    dim3 grid((d.M + BM - 1) / BM, (d.n_store + BN - 1) / BN,
+              d.nsplit * d.nbatch);
+    GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, d.nsplit, d.n_store};
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, BM, BN>), grid, dim3(256), 0, st, d.A, d.lda, d.B,
+                       d.ldb, d.C, d.ldc, d.M, d.Nn, d.K, kps, d.fix, gb);
+}
+
+template <bool AK, bool BK_>
+static void launch_layout(const GemmDesc &d, int kps, hipStream_t st) {
+    const bool m64 = d.M <= 64, n64 = d.n_store <= 64;
+    if (m64 && n64) launch_tile<AK, BK_, 64, 64>(d, kps, st);
+    else if (m64) launch_tile<AK, BK_, 64, 128>(d, kps, st);
+    else if (n64) launch_tile<AK, BK_, 128, 64>(d, kps, st);
+    else launch_tile<AK, BK_, 128, 128>(d, kps, st);
+}
+
+int launch_gemm(const GemmDesc &d0, hipStream_t st) {
+    GemmDesc d = d0;
+    if (d.n_store < d.Nn) d.n_store = d.Nn;
+    if (d.nbatch < 1) d.nbatch = 1;
+    if (d.nsplit < 1) d.nsplit = 1;
+    if (d.M == 0 || d.Nn == 0) return GATMI_OK;
+    GATMI_REQUIRE((long long)d.nsplit * d.nbatch <= 65535, "gemm: %d splits x %d batches", d.nsplit,
+                  d.nbatch);
+    const int kps = ((d.K + d.nsplit - 1) / d.nsplit + BK - 1) / BK * BK;
+    if (!d.a_kmajor && !d.b_kmajor) launch_layout<false, false>(d, kps, st);
+    else if (!d.a_kmajor && d.b_kmajor) launch_layout<false, true>(d, kps, st);
+    else if (d.a_kmajor && d.b_kmajor) launch_layout<true, true>(d, kps, st);
+    else {
+        set_error("gemm: A k-major with B n-major is not built");
+        return GATMI_ERR_ARG;
+    }
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
 
+static int launch_gemm(bool a_km, bool b_km, const float *A, int lda, const float *B, int ldb,
+                       float *C, int ldc, int M, int Nn, int K, int nsplit, hipStream_t st,
+                       AFix fix = AFix{nullptr, nullptr, 1, 1}) {
+    GemmDesc d{};
+    d.a_kmajor = a_km; d.b_kmajor = b_km;
+    d.A = A; d.lda = lda; d.B = B; d.ldb = ldb; d.C = C; d.ldc = ldc;
+    d.M = M; d.Nn = Nn; d.K = K; d.n_store = Nn; d.nbatch = 1; d.nsplit = nsplit;
+    d.sSplit = (long long)M * ldc;
+    d.fix = fix;
+    return launch_gemm(d, st);
+}
+
 static int dweight_splits(int N, int Dp, int F) {
-    const int tiles = ((Dp + BM - 1) / BM) * ((F + BN - 1) / BN);
+    const int tiles = ((Dp + 127) / 128) * ((F + 127) / 128);
     int want = 512 / tiles;   // ~512 blocks: enough to fill 256 CUs, half the slab traffic of 1024
     const int maxs = (N + 4 * BK - 1) / (4 * BK);
     if (want > maxs) want = maxs;

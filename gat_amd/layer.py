@@ -48,6 +48,35 @@ class _GATConvFn(torch.autograd.Function):
         return d_x, d_w, d_as.view(ctx.att_shape), d_ad.view(ctx.att_shape), d_b, None, None
 
 
+class _GATConvInAggFn(torch.autograd.Function):
+    """The same layer for an input that needs no gradient and is narrower than the output:
+    aggregate the x rows per head first, project afterwards (gat_amd/csrc/inagg.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, att_src, att_dst, bias, layout: GraphLayout, cfg: ops.AttnConfig):
+        n = x.size(0)
+        if layout.num_nodes != n or layout.num_dst != n:
+            raise ValueError(f"graph has {layout.num_nodes} nodes but x has {n} rows")
+        x = x.contiguous()
+        weight = weight.contiguous()
+        att_s = att_src.contiguous().view(-1)
+        att_d = att_dst.contiguous().view(-1)
+        bias_c = None if bias is None else bias.contiguous()
+        need_grad = any(ctx.needs_input_grad[1:5])
+        out, z, lse = ops.inagg_fwd(layout, cfg, x, weight, att_s, att_d, bias_c, need_grad)
+        if need_grad:
+            ctx.save_for_backward(x, weight, att_s, att_d, bias_c, z, lse)
+            ctx.layout, ctx.cfg, ctx.att_shape = layout, cfg, att_src.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, att_s, att_d, bias_c, z, lse = ctx.saved_tensors
+        d_w, d_as, d_ad, d_b = ops.inagg_bwd(ctx.layout, ctx.cfg, x, weight, att_s, att_d, bias_c,
+                                             z, lse, grad_out.contiguous())
+        return None, d_w, d_as.view(ctx.att_shape), d_ad.view(ctx.att_shape), d_b, None, None
+
+
 def _glorot_(t: Tensor) -> Tensor:
     bound = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
     with torch.no_grad():
@@ -62,12 +91,16 @@ class GATConv(nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
                  negative_slope: float = 0.2, dropout: float = 0.0, add_self_loops: bool = True,
-                 bias: bool = True, seg_len: int = DEFAULT_SEG_LEN):
+                 bias: bool = True, seg_len: int = DEFAULT_SEG_LEN,
+                 input_aggregation: Optional[bool] = None):
         super().__init__()
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
         self.add_self_loops = add_self_loops
         self.seg_len = seg_len
+        # None: aggregate x before projecting whenever that is possible and cheaper (x needs
+        # no gradient, F < H*Cp); True/False force the choice (True raises when impossible)
+        self.input_aggregation = input_aggregation
         self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
         self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
@@ -104,8 +137,15 @@ class GATConv(nn.Module):
         fused_bias = self.bias if self.concat else None
         cfg = ops.AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
                              mask_mode, seed, mask)
-        out = _GATConvFn.apply(x, self.lin.weight, self.att_src, self.att_dst, fused_bias, layout,
-                               cfg)
+        x_grad = x.requires_grad and torch.is_grad_enabled()
+        use_inagg = self.input_aggregation
+        if use_inagg is None:
+            use_inagg = not x_grad and ops.inagg_supported(self.in_channels, self.heads,
+                                                           self.out_channels)
+        elif use_inagg and x_grad:
+            raise RuntimeError("input_aggregation=True cannot produce a gradient for x")
+        fn = _GATConvInAggFn if use_inagg else _GATConvFn
+        out = fn.apply(x, self.lin.weight, self.att_src, self.att_dst, fused_bias, layout, cfg)
         if not self.concat:
             out = out.view(-1, self.heads, self.out_channels).mean(dim=1)
             if self.bias is not None:

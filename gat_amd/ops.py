@@ -127,3 +127,63 @@ def add_dst_term(d_hp: Tensor, d_a_dst: Tensor, att_dst: Tensor, heads: int, cha
     with torch.cuda.device(dev):
         _lib.check(lib.gatmi_add_dst_term(C.byref(shape), d_hp.data_ptr(), d_a_dst.data_ptr(),
                                           att_dst.data_ptr(), _stream(dev)), "gatmi_add_dst_term")
+
+
+# ------------------------------------------------------------------ input-side aggregation
+def inagg_supported(in_features: int, heads: int, channels: int) -> bool:
+    """True when the input-side aggregation kernels cover this layer AND it pays: an x row is
+    narrower than a projected row (F < H*Cp)."""
+    shape = _lib.Shape(0, in_features, heads, channels)
+    return (in_features < heads * padded_channels(channels)
+            and bool(_lib.lib().gatmi_inagg_supported(C.byref(shape))))
+
+
+def _inagg_args(cfg: AttnConfig, num_dst, x, weight, att_src, att_dst, bias):
+    a = _lib.InAgg()
+    a.shape = _lib.Shape(num_dst, x.size(1), cfg.heads, cfg.channels)
+    a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
+    a.mask_mode, a.seed, a.mask = cfg.mask_mode, cfg.seed, _ptr(cfg.mask)
+    a.x, a.weight = x.data_ptr(), weight.data_ptr()
+    a.att_src, a.att_dst, a.bias = _ptr(att_src), _ptr(att_dst), _ptr(bias)
+    return a
+
+
+def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, x: Tensor, weight: Tensor, att_src: Tensor,
+              att_dst: Tensor, bias: Optional[Tensor], need_lse: bool
+              ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """x [num_src, F] (all nodes) -> out [num_dst, H*C], z [num_dst, H*Fp], lse [num_dst, H]."""
+    lib, dev = _lib.lib(), x.device
+    n = layout.num_dst
+    if x.size(0) != layout.num_nodes:
+        raise ValueError(f"x has {x.size(0)} rows, the graph {layout.num_nodes} source nodes")
+    with torch.cuda.device(dev):
+        a = _inagg_args(cfg, n, x, weight, att_src, att_dst, bias)
+        zf = int(lib.gatmi_inagg_z_floats(C.byref(a.shape)))
+        if zf == 0:
+            raise RuntimeError(f"input-side aggregation does not cover F={x.size(1)} H={cfg.heads}")
+        out = torch.empty(n, cfg.heads * cfg.channels, dtype=torch.float32, device=dev)
+        z = torch.empty(n, zf, dtype=torch.float32, device=dev)
+        lse = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev) if need_lse else None
+        ws = _ws(lib.gatmi_inagg_fwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
+        _lib.check(lib.gatmi_inagg_fwd(layout.ref, C.byref(a), out.data_ptr(), z.data_ptr(),
+                                       _ptr(lse), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "gatmi_inagg_fwd")
+    return out, z, lse
+
+
+def inagg_bwd(layout: GraphLayout, cfg: AttnConfig, x: Tensor, weight: Tensor, att_src: Tensor,
+              att_dst: Tensor, bias: Optional[Tensor], z: Tensor, lse: Tensor, grad_out: Tensor):
+    """-> d_weight, d_att_src, d_att_dst, d_bias (partial sums on a destination partition)."""
+    lib, dev = _lib.lib(), x.device
+    with torch.cuda.device(dev):
+        a = _inagg_args(cfg, layout.num_dst, x, weight, att_src, att_dst, bias)
+        d_w = torch.empty_like(weight)
+        d_as = torch.empty_like(att_src)
+        d_ad = torch.empty_like(att_dst)
+        d_b = torch.empty_like(bias) if bias is not None else None
+        ws = _ws(lib.gatmi_inagg_bwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
+        _lib.check(lib.gatmi_inagg_bwd(layout.ref, C.byref(a), z.data_ptr(), lse.data_ptr(),
+                                       grad_out.data_ptr(), d_w.data_ptr(), d_as.data_ptr(),
+                                       d_ad.data_ptr(), _ptr(d_b), ws.data_ptr(), ws.numel(),
+                                       _stream(dev)), "gatmi_inagg_bwd")
+    return d_w, d_as, d_ad, d_b

@@ -186,6 +186,48 @@ int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
 int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float *d_a_dst,
                        const float *att_dst, void *stream);
 
+/* ---- Input-side aggregation: the same layer call (model.py:40, rows a5-a11) for a layer
+ * whose input needs no gradient -- the reference's conv1, whose x is `data.x` (model.py:38-40)
+ * -- and whose rows are narrower than its output (F < H*Cp).  The projection moves behind
+ * the aggregation,
+ *     out[i,h,:] = W_h (sum_e alpha~_e x_j) + bias_h,    a_src[j,h] = <x_j, W_h^T att_src_h>,
+ * so every edge gathers an x row (F floats) instead of a projected row (H*C floats); the
+ * backward runs on the destination CSR alone and yields the parameter gradients (there is
+ * no d_x).  Results equal gatmi_project_fwd + gatmi_attn_fwd up to fp32 re-association. */
+typedef struct gatmi_inagg {
+    gatmi_shape shape;     /* num_nodes = destination rows                              */
+    float negative_slope;
+    float dropout_p;
+    int32_t mask_mode;     /* GATMI_MASK_*                                              */
+    int32_t _pad;
+    uint64_t seed;
+    const uint8_t *mask;   /* GATMI_MASK_BYTES: [E', H] keep flags, dst-CSR order       */
+    const float *x;        /* [num_src, F] input rows (all nodes of the graph)          */
+    const float *weight;   /* [H*C, F]                                                  */
+    const float *att_src;  /* [H*C]                                                     */
+    const float *att_dst;  /* [H*C]                                                     */
+    const float *bias;     /* [H*C] or NULL                                             */
+} gatmi_inagg;
+
+/* 1 when the kernels cover this (F, H): H <= 32 and round_up(F,4)/4 <= 4 * 64/next_pow2(H). */
+int gatmi_inagg_supported(const gatmi_shape *s);
+/* Floats per destination row of the aggregated-input table z: H * round_up(F, 4). */
+size_t gatmi_inagg_z_floats(const gatmi_shape *s);
+
+/*   -> out [num_dst, H*C],  z [num_dst, H*round_up(F,4)] (kept for the backward),
+ *      lse [num_dst, H] (NULL when no backward follows)                                 */
+size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
+int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float *out, float *z, float *lse,
+                    void *ws, size_t ws_bytes, void *stream);
+
+/*   z, lse: what gatmi_inagg_fwd produced;  grad_out [num_dst, H*C]
+ *   -> d_weight [H*C, F], d_att_src [H*C], d_att_dst [H*C], d_bias [H*C] (NULL to skip).
+ * On a destination partition these are the rank's partial sums (all-reduce them).      */
+size_t gatmi_inagg_bwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
+int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const float *z, const float *lse,
+                    const float *grad_out, float *d_weight, float *d_att_src, float *d_att_dst,
+                    float *d_bias, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

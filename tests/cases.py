@@ -71,6 +71,12 @@ SHAPES = {
     "odd_c40": (12, 4, 40),
     "wide_t2": (9, 8, 40),
     "three_heads": (6, 3, 5),
+    # input layers narrower than their output (the input-side aggregation path)
+    "products_l1": (100, 4, 64),  # BASELINE.json config 5
+    "arxiv_l1": (128, 4, 64),     # config 3, layer 1
+    "in_t4": (200, 4, 64),
+    "in_one_head": (5, 1, 16),
+    "in_odd": (7, 5, 9),
 }
 
 

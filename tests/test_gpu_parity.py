@@ -130,10 +130,13 @@ def test_projection_fwd_bwd(cuda, n, f, h, c):
 
 
 # ------------------------------------------------------------------ whole layer
-def run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs=None, concat=True):
+def run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs=None, concat=True, inagg=False):
+    """inagg=True: x carries no gradient and the layer must take the input-side aggregation
+    path (gatmi_inagg_*); the returned grads then have no "x" entry."""
     from gat_amd import GATConv
     x, w, a_s, a_d, b, go = inputs if inputs is not None else cases.layer_inputs(n, f, h, c)
-    conv = GATConv(f, c, heads=h, dropout=p, seg_len=seg).to(cuda)
+    conv = GATConv(f, c, heads=h, dropout=p, seg_len=seg,
+                   input_aggregation=True if inagg else False).to(cuda)
     with torch.no_grad():
         conv.lin.weight.copy_(w)
         conv.att_src.copy_(a_s)
@@ -141,11 +144,13 @@ def run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs=None, concat=True):
         conv.bias.copy_(b)
     conv.train(p > 0)
     conv.injected_mask = mask
-    xd = x.to(cuda).requires_grad_(True)
+    xd = x.to(cuda).requires_grad_(not inagg)
     out = conv(xd, ei.to(cuda))
     out.backward(go.to(cuda))
-    grads = dict(x=xd.grad, weight=conv.lin.weight.grad, att_src=conv.att_src.grad,
+    grads = dict(weight=conv.lin.weight.grad, att_src=conv.att_src.grad,
                  att_dst=conv.att_dst.grad, bias=conv.bias.grad)
+    if not inagg:
+        grads["x"] = xd.grad
     return out, grads
 
 
@@ -176,6 +181,103 @@ def test_layer_matches_oracle(cuda, gname, sname, p, seg):
     summand = float(go.abs().max() * (x @ w.t()).abs().max())
     for k in ref_g:
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
+INAGG_CASES = [
+    ("knn", "conv1_h30", 0.425, 512), ("knn", "products_l1", 0.425, 512), ("knn", "arxiv_l1", 0.0, 512),
+    ("multigraph", "conv1_h30", 0.0, 64), ("multigraph", "products_l1", 0.3, 64),
+    ("multigraph", "three_heads", 0.5, 512), ("multigraph", "wide_t2", 0.2, 64),
+    ("multigraph", "in_odd", 0.3, 64), ("multigraph", "in_one_head", 0.0, 64),
+    ("star", "products_l1", 0.4, 64), ("star", "conv1_h30", 0.0, 64), ("star", "in_t4", 0.3, 64),
+    ("star", "odd_c40", 0.0, 128), ("hub_source", "arxiv_l1", 0.425, 64),
+    ("hub_source", "in_odd", 0.0, 64), ("chain", "in_t4", 0.0, 512), ("chain", "products_l1", 0.35, 512),
+    ("empty", "products_l1", 0.0, 512), ("empty", "conv1_h30", 0.5, 64),
+]
+
+
+@pytest.mark.parametrize("gname,sname,p,seg", INAGG_CASES)
+def test_input_aggregation_matches_oracle(cuda, gname, sname, p, seg):
+    """The input-side aggregation path (x without gradient, F < H*Cp): output and parameter
+    gradients against the same oracle as the projected-row path."""
+    ei, n = cases.GRAPHS[gname]()
+    f, h, c = cases.SHAPES[sname]
+    inputs = cases.layer_inputs(n, f, h, c)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                              mask=mask, training=p > 0)
+    out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=True)
+    close(out, ref_out, "out")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
+def test_input_aggregation_is_chosen_and_agrees_with_projected_rows(cuda):
+    """auto mode: x without grad and F < H*Cp -> gatmi_inagg_*; with grad -> projected rows;
+    both agree to fp32 re-association; hash dropout draws the same mask on both."""
+    from gat_amd import GATConv, _lib
+    ei, n = cases.knn_graph(n=700, f=6, seed=4)
+    f, h, c = cases.SHAPES["products_l1"]
+    x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c, seed=4)
+    conv = GATConv(f, c, heads=h, dropout=0.3).to(cuda).train()
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
+    res = []
+    for need_dx in (False, True):
+        conv.zero_grad()
+        torch.manual_seed(5)
+        xd = x.to(cuda).requires_grad_(need_dx)
+        _lib.prof_read(); _lib.prof_enable(True)
+        out = conv(xd, ei.to(cuda))
+        out.backward(go.to(cuda))
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        tags = {t for t, _ in _lib.prof_read()}
+        assert ("inagg_fwd" in tags) == (not need_dx), tags
+        assert ("attn_fwd" in tags) == need_dx, tags
+        res.append((out.detach(), conv.lin.weight.grad.clone(), conv.att_src.grad.clone(),
+                    conv.att_dst.grad.clone(), conv.bias.grad.clone()))
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for a, bb, name in zip(res[0], res[1], ["out", "d_weight", "d_att_src", "d_att_dst", "d_bias"]):
+        close(a, bb, name, floor=summand if "att" in name else 0.0)
+
+
+def test_input_aggregation_random_sweep(cuda):
+    import random
+    rng = random.Random(4321)
+    from gat_amd import ops
+    done = 0
+    for trial in range(60):
+        n = rng.choice([1, 2, 3, 17, 64, 65, 200, 333])
+        e = rng.choice([0, 1, n, 5 * n, 20 * n])
+        h = rng.choice([1, 2, 3, 4, 5, 8])
+        c = rng.choice([2, 4, 7, 8, 16, 30, 33, 64])
+        f = rng.choice([1, 3, 4, 16, 25, 100, 130])
+        if not ops.inagg_supported(f, h, c):
+            continue
+        p = rng.choice([0.0, 0.0, 0.3, 0.6])
+        seg = rng.choice([64, 128, 512])
+        g = torch.Generator().manual_seed(trial)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        if e > 4:
+            ei[1, : e // 3] = ei[1, 0]
+            ei[0, e // 3: e // 2] = ei[0, -1]
+        inputs = cases.layer_inputs(n, f, h, c, seed=trial)
+        x, w, a_s, a_d, b, go = inputs
+        ne = O.build_csr(ei, n).num_edges
+        mask = cases.keep_mask(ne, h, p, seed=trial) if p > 0 else None
+        ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                                  mask=mask, training=p > 0)
+        out, gr = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=True)
+        tag = f"trial {trial}: n={n} e={e} h={h} c={c} f={f} p={p} seg={seg}"
+        close(out, ref_out, tag + " out")
+        summand = float(go.abs().max() * (x @ w.t()).abs().max())
+        for k in gr:
+            close(gr[k], ref_g[k], f"{tag} d_{k}", floor=summand if k.startswith("att") else 0.0)
+        done += 1
+    assert done >= 20
 
 
 def test_layer_error_vs_fp64_is_oracle_sized(cuda):
