@@ -51,8 +51,9 @@ class Attn(C.Structure):
 class InAgg(C.Structure):
     _fields_ = [("shape", Shape), ("negative_slope", C.c_float), ("dropout_p", C.c_float),
                 ("mask_mode", C.c_int32), ("_pad", C.c_int32), ("seed", C.c_uint64),
-                ("mask", C.c_void_p), ("x", C.c_void_p), ("weight", C.c_void_p),
-                ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
+                ("mask", C.c_void_p), ("xs", C.c_void_p), ("a_dst", C.c_void_p),
+                ("weight", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p),
+                ("bias", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/gat_mi355.h declares
@@ -84,6 +85,10 @@ SYMBOLS = {
                                      C.c_void_p]),
     "gatmi_inagg_supported": (C.c_int, [C.POINTER(Shape)]),
     "gatmi_inagg_z_floats": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_inagg_xs_floats": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_inagg_pack_workspace_bytes": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_inagg_pack": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_inagg_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_inagg_fwd": (C.c_int, [C.POINTER(Graph), C.POINTER(InAgg), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

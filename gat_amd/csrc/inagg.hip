@@ -21,29 +21,83 @@
 // consecutive lanes of a head hold T float4 of the x row each (sub = sl + t*LH), every head
 // group reads the same row.  Per-head dots are butterflies over LH lanes.
 #ifndef GATMI_INAGG_U2
-#define GATMI_INAGG_U2 2
+#define GATMI_INAGG_U2 4
 #endif
 #include "attn_device.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace gatmi {
+
+// packed-f32 helpers: v_pk_fma_f32 does two lanes-worth of fp32 FMA per issue slot, and the
+// edge loops below are VALU-issue bound (an x row is short), so the 4-wide row arithmetic is
+// written on 2-vectors explicitly (the build runs with -fno-slp-vectorize)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f2 lo2(const f4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f2 hi2(const f4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ void pk_fma4(f4 &acc, float s, const f4 v) {
+    const f2 s2 = {s, s};
+    const f2 a = __builtin_elementwise_fma(s2, lo2(v), lo2(acc));
+    const f2 b = __builtin_elementwise_fma(s2, hi2(v), hi2(acc));
+    acc = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+}
+__device__ __forceinline__ void pk_dot4(f2 &d, const f4 a, const f4 b) {
+    d = __builtin_elementwise_fma(lo2(a), lo2(b), d);
+    d = __builtin_elementwise_fma(hi2(a), hi2(b), d);
+}
+__device__ __forceinline__ void pk_scale4(f4 &acc, float s) {
+    const f2 s2 = {s, s};
+    const f2 a = lo2(acc) * s2, b = hi2(acc) * s2;
+    acc = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f4 ldv4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ void stv4(float *p, const f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ f4 zero4() { return f4{0.f, 0.f, 0.f, 0.f}; }
+
+// 16 bytes / 4 bytes of row j of the packed table at a lane byte offset (see ld4_row)
+template <int G>
+__device__ __forceinline__ f4 ldv4_row(const float *table, int j, int row_floats, unsigned off_bytes) {
+    const char *rowp = reinterpret_cast<const char *>(table) + (size_t)j * (size_t)row_floats * 4;
+    if constexpr (G == 64) {
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(rowp), 0, row_floats * 4, 0x00020000);
+        return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_bytes, 0, 0));
+    } else {
+        return *reinterpret_cast<const f4 *>(rowp + off_bytes);
+    }
+}
+template <int G>
+__device__ __forceinline__ float ld1_row(const float *table, int j, int row_floats, unsigned off_bytes) {
+    const char *rowp = reinterpret_cast<const char *>(table) + (size_t)j * (size_t)row_floats * 4;
+    if constexpr (G == 64) {
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(rowp), 0, row_floats * 4, 0x00020000);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off_bytes, 0, 0));
+    } else {
+        return *reinterpret_cast<const float *>(rowp + off_bytes);
+    }
+}
 
 struct InArgs {
     const int *rowptr, *col, *item_row, *item_beg, *item_slot;
     int n_items, seg_len;
-    int H, Fp, lph, lh_log, dst_off;
+    int H, Fp, Fs, lph, lh_log, dst_off;
     float neg_slope, inv_keep;
     uint32_t keep_thr;
     int mask_mode;
     const uint8_t *mask;
     uint64_t seed;
-    const float *xp;    // [num_src, Fp]
-    const float *wsd;   // [2][H*Fp]: ws, wd (padded columns zero)
+    const float *xs;     // [num_src, Fs]: x row (Fp floats, zero padded) | a_src (H floats) | pad
+    const float *a_dst;  // [num_dst, H]
     // forward
     float *z, *lse, *part_m, *part_s, *part_acc;
     // backward
     const float *q, *zin, *lsein;
-    float *part_y;      // [waves][2][H*Fp]
+    float *part_y;       // [waves][2][H*Fp]
+    // streaming kernels (LDS-DMA ring): chunk queue
+    int *queue;
+    int n_chunks, E;
 };
 
 #define INAGG_PROLOGUE                                                                    \
@@ -58,15 +112,13 @@ struct InArgs {
     bool ok[T];                                                                           \
     unsigned offb[T];                                                                     \
     int roff[T];                                                                          \
-    float4 ws4[T], wd4[T];                                                                \
     _Pragma("unroll") for (int t = 0; t < T; ++t) {                                       \
         const int sub = sl + t * lh;                                                      \
         ok[t] = hok && sub < A.lph;                                                       \
         offb[t] = ok[t] ? (unsigned)sub * 16u : 0u;                                       \
         roff[t] = ok[t] ? head * A.Fp + sub * 4 : 0;                                      \
-        ws4[t] = ok[t] ? ld4(A.wsd + roff[t]) : make_float4(0.f, 0.f, 0.f, 0.f);          \
-        wd4[t] = ok[t] ? ld4(A.wsd + HF + roff[t]) : make_float4(0.f, 0.f, 0.f, 0.f);     \
     }                                                                                     \
+    const unsigned aoff = (unsigned)(A.Fp + head) * 4u;                                   \
     const unsigned hbit = 1u << head;                                                     \
     constexpr int GPB = 256 / G;                                                          \
     const int stride = gridDim.x * GPB;
@@ -79,50 +131,42 @@ struct InArgs {
         const int slot = uniform<G>(A.item_slot[it]);                                     \
         int end = uniform<G>(A.rowptr[row + 1]);                                          \
         end = min(end, beg + A.seg_len);                                                  \
-        float4 xi[T];                                                                     \
-        float adi = 0.f;                                                                  \
-        _Pragma("unroll") for (int t = 0; t < T; ++t) {                                   \
-            xi[t] = ok[t] ? ld4(A.xp + (size_t)(row + A.dst_off) * A.Fp + (offb[t] >> 2)) \
-                          : make_float4(0.f, 0.f, 0.f, 0.f);                              \
-            adi += dot4(xi[t], wd4[t]);                                                   \
-        }                                                                                 \
-        adi = head_sum<LH_T>(adi, lh);
+        const float adi = A.a_dst[(size_t)row * A.H + head];
 
 // ---------------------------------------------------------------------------------
 // Forward: online softmax over the row's edges, Z[i,h,:] = sum_e alpha~_e x_j, lse.
-// Same pipeline as attn_fwd_kernel (double-buffered branch-free gathers).
+// Same pipeline as attn_fwd_kernel (double-buffered branch-free gathers); the source logit
+// rides in the gathered row (one dword per lane at the end of it).
 // ---------------------------------------------------------------------------------
 template <int LH_T, int G, int T>
 __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
-    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 1);
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 2);
     INAGG_PROLOGUE
     INAGG_ITEM_LOOP
         float m = -INFINITY, ssum = 0.f;
-        float4 acc[T];
+        f4 acc[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < T; ++t) acc[t] = zero4();
         for (int c = beg; c < end; c += G) {
             const int n = min(G, end - c);
             const int cl = min(lig, n - 1);
             const int cj = A.col[c + cl];
             const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
-            auto load = [&](float4(&v)[U][T], int k0) {
+            auto load = [&](f4(&v)[U][T], float(&as)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) v[u][t] = ld4_row<G>(A.xp, j, A.Fp, offb[t]);
+                    for (int t = 0; t < T; ++t) v[u][t] = ldv4_row<G>(A.xs, j, A.Fs, offb[t]);
+                    as[u] = ld1_row<G>(A.xs, j, A.Fs, aoff);
                 }
             };
-            auto reduce = [&](const float4(&v)[U][T], int k0) {
+            auto reduce = [&](const f4(&v)[U][T], const float(&as)[U], int k0) {
                 float z[U];
                 float mn = m;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    float d = 0.f;
-#pragma unroll
-                    for (int t = 0; t < T; ++t) d += dot4(v[u][t], ws4[t]);
-                    const float uu = head_sum<LH_T>(d, lh) + adi;
+                    const float uu = as[u] + adi;
                     const float zz = uu > 0.f ? uu : A.neg_slope * uu;
                     z[u] = (k0 + u < n) ? zz : -INFINITY;
                     mn = fmaxf(mn, z[u]);
@@ -130,7 +174,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
                 const float sc = exp_fast(m - mn);
                 ssum *= sc;
 #pragma unroll
-                for (int t = 0; t < T; ++t) scale4(acc[t], sc);
+                for (int t = 0; t < T; ++t) pk_scale4(acc[t], sc);
                 m = mn;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -140,16 +184,17 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
                     ssum += p;
                     const float w = (sb & hbit) ? p * A.inv_keep : 0.f;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) fma4(acc[t], w, v[u][t]);
+                    for (int t = 0; t < T; ++t) pk_fma4(acc[t], w, v[u][t]);
                 }
             };
-            float4 va[U][T], vb[U][T];
-            load(va, 0);
+            f4 va[U][T], vb[U][T];
+            float sa[U], sb_[U];
+            load(va, sa, 0);
             for (int k0 = 0; k0 < n; k0 += 2 * U) {
-                load(vb, k0 + U);
-                reduce(va, k0);
-                load(va, k0 + 2 * U);
-                reduce(vb, k0 + U);
+                load(vb, sb_, k0 + U);
+                reduce(va, sa, k0);
+                load(va, sa, k0 + 2 * U);
+                reduce(vb, sb_, k0 + U);
             }
         }
         if (slot < 0) {
@@ -157,20 +202,253 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (ok[t]) {
-                    float4 o = acc[t];
-                    scale4(o, inv);
-                    st4(A.z + (size_t)row * HF + roff[t], o);
+                    f4 o = acc[t];
+                    pk_scale4(o, inv);
+                    stv4(A.z + (size_t)row * HF + roff[t], o);
                 }
             if (A.lse && hok && sl == 0) A.lse[(size_t)row * A.H + head] = m + logf(ssum);
         } else {
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                if (ok[t]) st4(A.part_acc + (size_t)slot * HF + roff[t], acc[t]);
+                if (ok[t]) stv4(A.part_acc + (size_t)slot * HF + roff[t], acc[t]);
             if (hok && sl == 0) {
                 A.part_m[(size_t)slot * A.H + head] = m;
                 A.part_s[(size_t)slot * A.H + head] = ssum;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Streaming forward (G == 64).  The register pipeline above keeps every gathered row four
+// times in VGPRs (once per head group), which caps the bytes in flight per CU at ~40 KB and
+// the kernel at ~3 TB/s for 400-B rows.  Here the rows travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, one copy per row, no VGPRs) through a per-wave ring of 1-KiB
+// slots; the head groups read their pieces back with ds_read_b128.
+//
+//   chunk     kChunkItems consecutive work items, claimed from an atomic queue; their edges
+//             are one contiguous range [cb, ce) of the CSR
+//   producer  walks that range: one DMA instruction (a "stage") moves rpi = 64 / (Fs/4) rows,
+//             lane (er, ep) -> piece ep of the row of edge pe + er; stages restart at item
+//             boundaries.  col indices come from 64-entry windows DMA'd into LDS one window
+//             ahead, so no ordinary load result is ever needed while rows are in flight
+//             (hipcc drains the DMA queue at such a use)
+//   consumer  per item and stage: tops the ring up, waits with a COUNTED vmcnt for its stage
+//             (loads retire in order; counting only the stages issued after it under-counts
+//             the younger operations, which only waits longer), reads the rows from LDS
+// Every loop is bounded by the chunk's item/edge counts; there is no spin-wait.
+// ---------------------------------------------------------------------------------
+#ifndef GATMI_RING
+#define GATMI_RING 4
+#endif
+constexpr int kChunkItems = 16;
+constexpr int kColWin = 4;   // col windows in the LDS ring (power of two, >= 4)
+constexpr int kStreamMaxHeads = 8;
+
+__device__ __forceinline__ void dma16(const void *g, void *lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_uniform, 16,
+                                     0, 0);
+}
+__device__ __forceinline__ void dma4(const void *g, void *lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_uniform, 4,
+                                     0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vm_imm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most n (wave-uniform) vector-memory operations are outstanding
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: wait_vm_imm<0>(); break;
+        case 1: wait_vm_imm<1>(); break;
+        case 2: wait_vm_imm<2>(); break;
+        case 3: wait_vm_imm<3>(); break;
+        case 4: wait_vm_imm<4>(); break;
+        case 5: wait_vm_imm<5>(); break;
+        case 6: wait_vm_imm<6>(); break;
+        case 7: wait_vm_imm<7>(); break;
+        case 8: wait_vm_imm<8>(); break;
+        case 9: wait_vm_imm<9>(); break;
+        case 10: wait_vm_imm<10>(); break;
+        case 11: wait_vm_imm<11>(); break;
+        case 12: wait_vm_imm<12>(); break;
+        case 13: wait_vm_imm<13>(); break;
+        case 14: wait_vm_imm<14>(); break;
+        default: wait_vm_imm<15>(); break;
+    }
+}
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Shared by the streaming forward and backward: chunk claim, metadata, col windows, producer.
+#define STREAM_PROLOGUE                                                                   \
+    constexpr int G = 64, R = GATMI_RING, CH = kChunkItems;                               \
+    __shared__ __attribute__((aligned(16))) char s_ring[4][R * 1024];                     \
+    __shared__ int s_col[4][kColWin * 64];                                                \
+    INAGG_PROLOGUE                                                                        \
+    (void)gbase; (void)stride; (void)lig;                                                 \
+    const int wv = threadIdx.x >> 6;                                                      \
+    char *ring = s_ring[wv];                                                              \
+    int *colr = s_col[wv];                                                                \
+    const int nf4 = A.Fs >> 2, rpi = 64 / nf4;                                            \
+    const int er = lane / nf4, ep = lane - er * nf4;                                      \
+    const bool dma_on = er < rpi;                                                         \
+    const unsigned rstride = (unsigned)nf4 * 16u;                                         \
+    const size_t row_bytes = (size_t)A.Fs * 4;
+
+#define STREAM_CLAIM_CHUNK                                                                \
+    int k = 0;                                                                            \
+    if (lane == 0) k = atomicAdd(A.queue, 1);                                             \
+    k = __builtin_amdgcn_readfirstlane(k);                                                \
+    if (k >= A.n_chunks) break;                                                           \
+    const int i0 = k * CH, ni = min(CH, A.n_items - i0);                                  \
+    const int il = i0 + lane;                                                             \
+    const int vbeg = lane <= ni ? (il < A.n_items ? A.item_beg[il] : A.E) : 0;            \
+    const int vrow = lane < ni ? A.item_row[il] : 0;                                      \
+    const int vslot = lane < ni ? A.item_slot[il] : -1;                                   \
+    const int cb = __builtin_amdgcn_readlane(vbeg, 0);                                    \
+    const int ce = __builtin_amdgcn_readlane(vbeg, ni);
+
+template <int LH_T, int T>
+__global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
+    STREAM_PROLOGUE
+    __shared__ float s_adst[4][kChunkItems * kStreamMaxHeads];
+    float *adl = s_adst[wv];
+    for (;;) {
+        STREAM_CLAIM_CHUNK
+        for (int t0 = 0; t0 < ni * A.H; t0 += 64) {
+            const int t = t0 + lane;
+            const int itx = min(t / A.H, ni - 1);
+            const int r = __shfl(vrow, itx, 64);
+            if (t < ni * A.H) adl[t] = A.a_dst[(size_t)r * A.H + (t - itx * A.H)];
+        }
+        // col windows 0 and 1
+        int wiss = 0;
+        auto issue_win = [&]() {
+            const int e = min(cb + wiss * 64 + lane, A.E - 1);
+            dma4(A.col + e, colr + (wiss & (kColWin - 1)) * 64);
+            ++wiss;
+        };
+        if (ce > cb) {
+            issue_win();
+            if (ce - cb > 64) issue_win();
+        }
+        wait_vm_imm<0>();
+        // producer
+        int Pst = 0, Cst = 0, pi = 0, pe = cb, pend = __builtin_amdgcn_readlane(vbeg, 1);
+        int wcur = 0, st_since = 0;
+        auto produce = [&]() {
+            while (pe >= pend) {
+                ++pi;
+                if (pi >= ni) return;
+                pend = __builtin_amdgcn_readlane(vbeg, pi + 1);
+            }
+            const int ehi = min(pe + rpi, pend) - 1;
+            const int wneed = (ehi - cb) >> 6;
+            if (wneed > wcur) {          // first stage that reads window wcur + 1
+                wait_vm(st_since);       // stages issued after that window's DMA
+                wcur = wneed;
+                if (wiss * 64 < ce - cb) {
+                    issue_win();
+                    st_since = 0;
+                }
+            }
+            wait_lds();                  // reads of the slot about to be refilled have landed
+            const int e = min(pe + er, ehi);
+            const int j = colr[(e - cb) & (kColWin * 64 - 1)];
+            const char *g = reinterpret_cast<const char *>(A.xs) + (size_t)j * row_bytes + ep * 16;
+            if (dma_on) dma16(g, ring + (Pst & (R - 1)) * 1024);
+            ++Pst;
+            ++st_since;
+            pe = ehi + 1;
+        };
+        for (int ci = 0; ci < ni; ++ci) {
+            const int row = __builtin_amdgcn_readlane(vrow, ci);
+            const int beg = __builtin_amdgcn_readlane(vbeg, ci);
+            const int end = __builtin_amdgcn_readlane(vbeg, ci + 1);
+            const int slot = __builtin_amdgcn_readlane(vslot, ci);
+            const float adi = adl[ci * A.H + head];
+            float m = -INFINITY, ssum = 0.f;
+            f4 acc[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = zero4();
+            int kbase = beg - 64, kb = 0;
+            for (int e0 = beg; e0 < end; e0 += rpi) {
+                while (Pst - Cst < R && pi < ni) produce();
+                wait_vm(Pst - Cst - 1);
+                const char *sb = ring + (Cst & (R - 1)) * 1024;
+                const int cnt = min(rpi, end - e0);
+                for (int r = 0; r < cnt; r += 2) {
+                    const int e = e0 + r;
+                    if (e - kbase >= 64) {
+                        kbase = e;
+                        kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+                                            (long long)min(e + lane, end - 1), A.H);
+                    }
+                    const bool two = r + 1 < cnt;
+                    const char *r0 = sb + r * rstride;
+                    const char *r1 = two ? r0 + rstride : r0;
+                    f4 v0[T], v1[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        v0[t] = *reinterpret_cast<const f4 *>(r0 + offb[t]);
+                        v1[t] = *reinterpret_cast<const f4 *>(r1 + offb[t]);
+                    }
+                    const float as0 = *reinterpret_cast<const float *>(r0 + aoff);
+                    const float as1 = *reinterpret_cast<const float *>(r1 + aoff);
+                    const float u0 = as0 + adi, u1 = as1 + adi;
+                    const float z0 = u0 > 0.f ? u0 : A.neg_slope * u0;
+                    const float z1 = two ? (u1 > 0.f ? u1 : A.neg_slope * u1) : -INFINITY;
+                    const float mn = fmaxf(m, fmaxf(z0, z1));
+                    const float sc = exp_fast(m - mn);
+                    const float p0 = exp_fast(z0 - mn);
+                    const float p1 = two ? exp_fast(z1 - mn) : 0.f;
+                    ssum = fmaf(ssum, sc, p0 + p1);
+                    // the second edge of the pair may sit in the next 64-edge mask window
+                    unsigned sb0 = (unsigned)__builtin_amdgcn_readlane(kb, e - kbase);
+                    unsigned sb1 = sb0;
+                    if (two) {
+                        if (e + 1 - kbase >= 64) {
+                            kbase = e + 1;
+                            kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+                                                (long long)min(e + 1 + lane, end - 1), A.H);
+                        }
+                        sb1 = (unsigned)__builtin_amdgcn_readlane(kb, e + 1 - kbase);
+                    }
+                    const float w0 = (sb0 & hbit) ? p0 * A.inv_keep : 0.f;
+                    const float w1 = (sb1 & hbit) ? p1 * A.inv_keep : 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        pk_scale4(acc[t], sc);
+                        pk_fma4(acc[t], w0, v0[t]);
+                        pk_fma4(acc[t], w1, v1[t]);
+                    }
+                    m = mn;
+                }
+                ++Cst;
+            }
+            if (slot < 0) {
+                const float inv = ssum > 0.f ? 1.0f / ssum : 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (ok[t]) {
+                        f4 o = acc[t];
+                        pk_scale4(o, inv);
+                        stv4(A.z + (size_t)row * HF + roff[t], o);
+                    }
+                if (A.lse && hok && sl == 0) A.lse[(size_t)row * A.H + head] = m + logf(ssum);
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (ok[t]) stv4(A.part_acc + (size_t)slot * HF + roff[t], acc[t]);
+                if (hok && sl == 0) {
+                    A.part_m[(size_t)slot * A.H + head] = m;
+                    A.part_s[(size_t)slot * A.H + head] = ssum;
+                }
+            }
+        }
+        wait_lds();
     }
 }
 
@@ -206,23 +484,22 @@ __global__ __launch_bounds__(256) void inagg_fwd_merge_kernel(
 // ---------------------------------------------------------------------------------
 template <int LH_T, int G, int T>
 __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
-    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 1);
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 2);
     INAGG_PROLOGUE
-    float4 ys[T], yd[T];
+    f4 ys[T], yd[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) ys[t] = yd[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) ys[t] = yd[t] = zero4();
     INAGG_ITEM_LOOP
         (void)slot;
-        float4 q4[T];
-        float S = 0.f;
+        f4 q4[T];
+        f2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            q4[t] = ok[t] ? ld4(A.q + (size_t)row * HF + roff[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 z4 = ok[t] ? ld4(A.zin + (size_t)row * HF + roff[t])
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-            S += dot4(q4[t], z4);
+            q4[t] = ok[t] ? ldv4(A.q + (size_t)row * HF + roff[t]) : zero4();
+            const f4 z4 = ok[t] ? ldv4(A.zin + (size_t)row * HF + roff[t]) : zero4();
+            pk_dot4(s2, q4[t], z4);
         }
-        S = head_sum<LH_T>(S, lh);
+        const float S = head_sum<LH_T>(s2.x + s2.y, lh);
         const float lse_i = A.lsein[(size_t)row * A.H + head];
         float dad = 0.f;
         for (int c = beg; c < end; c += G) {
@@ -230,67 +507,69 @@ __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
             const int cl = min(lig, n - 1);
             const int cj = A.col[c + cl];
             const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
-            auto load = [&](float4(&v)[U][T], int k0) {
+            auto load = [&](f4(&v)[U][T], float(&as)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) v[u][t] = ld4_row<G>(A.xp, j, A.Fp, offb[t]);
+                    for (int t = 0; t < T; ++t) v[u][t] = ldv4_row<G>(A.xs, j, A.Fs, offb[t]);
+                    as[u] = ld1_row<G>(A.xs, j, A.Fs, aoff);
                 }
             };
-            auto reduce = [&](const float4(&v)[U][T], int k0) {
+            auto reduce = [&](const f4(&v)[U][T], const float(&as)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    float d1 = 0.f, d2 = 0.f;
+                    f2 d = {0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        d1 += dot4(v[u][t], ws4[t]);
-                        d2 += dot4(v[u][t], q4[t]);
-                    }
-                    d1 = head_sum<LH_T>(d1, lh);
-                    d2 = head_sum<LH_T>(d2, lh);
+                    for (int t = 0; t < T; ++t) pk_dot4(d, v[u][t], q4[t]);
+                    const float d2 = head_sum<LH_T>(d.x + d.y, lh);
                     const bool live = k0 + u < n;
                     const unsigned sb = (unsigned)group_bcast<G>(kb, min(k0 + u, n - 1), gbase);
-                    const float uu = d1 + adi;
+                    const float uu = as[u] + adi;
                     const float zz = uu > 0.f ? uu : A.neg_slope * uu;
                     const float alpha = live ? exp_fast(zz - lse_i) : 0.f;
                     const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
                     const float du = (at * d2 - alpha * S) * (uu > 0.f ? 1.0f : A.neg_slope);
                     dad += du;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) fma4(ys[t], du, v[u][t]);
+                    for (int t = 0; t < T; ++t) pk_fma4(ys[t], du, v[u][t]);
                 }
             };
-            float4 va[U][T], vb[U][T];
-            load(va, 0);
+            f4 va[U][T], vb[U][T];
+            float sa[U], sb_[U];
+            load(va, sa, 0);
             for (int k0 = 0; k0 < n; k0 += 2 * U) {
-                load(vb, k0 + U);
-                reduce(va, k0);
-                load(va, k0 + 2 * U);
-                reduce(vb, k0 + U);
+                load(vb, sb_, k0 + U);
+                reduce(va, sa, k0);
+                load(va, sa, k0 + 2 * U);
+                reduce(vb, sb_, k0 + U);
             }
         }
+        // d_wd += (sum of the row's d_u) * x_i
 #pragma unroll
-        for (int t = 0; t < T; ++t) fma4(yd[t], dad, xi[t]);
+        for (int t = 0; t < T; ++t) {
+            const f4 xi = ok[t] ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + (offb[t] >> 2)) : zero4();
+            pk_fma4(yd[t], dad, xi);
+        }
     }
     // fold the wave's 64/G row groups, then one partial row per wave
     if constexpr (G < 64) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            for (int o = G; o < 64; o <<= 1) {
-                ys[t].x += __shfl_xor(ys[t].x, o, 64); ys[t].y += __shfl_xor(ys[t].y, o, 64);
-                ys[t].z += __shfl_xor(ys[t].z, o, 64); ys[t].w += __shfl_xor(ys[t].w, o, 64);
-                yd[t].x += __shfl_xor(yd[t].x, o, 64); yd[t].y += __shfl_xor(yd[t].y, o, 64);
-                yd[t].z += __shfl_xor(yd[t].z, o, 64); yd[t].w += __shfl_xor(yd[t].w, o, 64);
-            }
+            for (int o = G; o < 64; o <<= 1)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ys[t][k] += __shfl_xor(ys[t][k], o, 64);
+                    yd[t][k] += __shfl_xor(yd[t][k], o, 64);
+                }
     }
     if (lane < G) {
         float *dst = A.part_y + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 * HF;
 #pragma unroll
         for (int t = 0; t < T; ++t)
             if (ok[t]) {
-                st4(dst + roff[t], ys[t]);
-                st4(dst + HF + roff[t], yd[t]);
+                stv4(dst + roff[t], ys[t]);
+                stv4(dst + HF + roff[t], yd[t]);
             }
     }
 }
@@ -312,13 +591,59 @@ __global__ void inagg_wsd_kernel(const float *w, const float *att_src, const flo
     }
 }
 
-// xp[n, 0..Fp) = x[n, 0..F), zero padded (only when F % 4 != 0)
-__global__ void inagg_pad_x_kernel(const float *x, float *xp, long long n, int F, int Fp) {
-    const long long tot = n * Fp;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int f = (int)(i % Fp);
-        xp[i] = f < F ? x[(i / Fp) * F + f] : 0.f;
+// Packed source table: xs[n] = x[n] (Fp floats, zero padded) | a_src[n, 0..H) | zero pad, and
+// a_dst[n, h] = <x[n], wd_h>.  A row is owned by gl = next_pow2(Fp/4) (<= 64) lanes, each holding
+// up to KS float4 of it; per-head dots are butterflies over those lanes.
+template <int KS>
+__global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const float *wsd, long long n,
+                                                         int F, int Fp, int Fs, int H, int glog,
+                                                         float *xs, float *a_dst) {
+    const int lane = threadIdx.x & 63, gl = 1 << glog, sl = lane & (gl - 1), rsub = lane >> glog;
+    const int rpw = 64 >> glog, lph = Fp >> 2, HF = H * Fp;
+    const bool vec = (F & 3) == 0;
+    const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6), nwaves = gridDim.x * 4ll;
+    for (long long row0 = wave * rpw; row0 < n; row0 += nwaves * rpw) {
+        const long long row = row0 + rsub;
+        const bool on = row < n;
+        f4 xv[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int sub = sl + k * gl;
+            xv[k] = zero4();
+            if (on && sub < lph) {
+                const float *src = x + row * F + sub * 4;
+                if (vec) {
+                    xv[k] = ldv4(src);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (sub * 4 + c < F) xv[k][c] = src[c];
+                }
+                stv4(xs + row * Fs + sub * 4, xv[k]);
+            }
+        }
+        for (int h = 0; h < H; ++h) {
+            f2 ds = {0.f, 0.f}, dd = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int sub = sl + k * gl;
+                if (sub < lph) {
+                    pk_dot4(ds, xv[k], ldv4(wsd + h * Fp + sub * 4));
+                    pk_dot4(dd, xv[k], ldv4(wsd + HF + h * Fp + sub * 4));
+                }
+            }
+            float a = ds.x + ds.y, d = dd.x + dd.y;
+            for (int o = 1; o < gl; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                d += __shfl_xor(d, o, 64);
+            }
+            if (on && sl == 0) {
+                xs[row * Fs + Fp + h] = a;
+                a_dst[row * H + h] = d;
+            }
+        }
+        if (on && sl == 0)
+            for (int h = H; h < Fs - Fp; ++h) xs[row * Fs + Fp + h] = 0.f;
     }
 }
 
@@ -410,12 +735,13 @@ __global__ __launch_bounds__(256) void inagg_finalize_kernel(
 // Host side
 // ---------------------------------------------------------------------------------
 struct InGeo {
-    int Fp, lph, H2, LH, lh_log, G, T, HF;
+    int Fp, Fs, lph, H2, LH, lh_log, G, T, HF;
 };
 
 static bool make_in_geo(const gatmi_shape &s, InGeo *g) {
     if (s.heads < 1 || s.heads > 32 || s.channels < 1 || s.in_features < 1) return false;
     g->Fp = round_up4(s.in_features);
+    g->Fs = g->Fp + round_up4(s.heads);
     g->lph = g->Fp / 4;
     g->H2 = next_pow2(s.heads);
     const int lmax = 64 / g->H2;
@@ -468,6 +794,48 @@ static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, h
     return GATMI_OK;
 }
 
+// Streaming (LDS-DMA) kernels: one row per wave (G == 64), a packed row fits one DMA
+// instruction (Fs/4 <= 64 lanes), per-chunk logit tables sized for <= kStreamMaxHeads heads.
+static bool stream_ok(const InGeo &g, int H) {
+    static const bool off = getenv("GATMI_NO_STREAM") != nullptr;   // A/B switch for benchmarks
+    return !off && g.G == 64 && g.Fs / 4 <= 64 && H <= kStreamMaxHeads;
+}
+
+// Persistent grid: as many blocks as fit on the device at once; chunks come from the queue.
+template <class K> static int resident_blocks(K kernel) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess)
+        return 1024;
+    if (cus < 1) cus = 256;
+    if (per < 1) per = 1;
+    return cus * per;
+}
+
+template <int LH_T, int T>
+static void stream_launch(InKind k, const InArgs &A, hipStream_t st) {
+    if (k == IN_FWD) {
+        static const int grid = resident_blocks(inagg_fwd_stream_kernel<LH_T, T>);
+        const int need = (A.n_chunks + 3) / 4;
+        hipLaunchKernelGGL((inagg_fwd_stream_kernel<LH_T, T>), dim3(need < grid ? need : grid),
+                           dim3(256), 0, st, A);
+    }
+}
+
+static int stream_launch_rows(InKind k, const InGeo &g, InArgs &A, hipStream_t st) {
+    A.n_chunks = (A.n_items + kChunkItems - 1) / kChunkItems;
+    if (A.n_chunks == 0) return GATMI_OK;
+    GATMI_HIP(hipMemsetAsync(A.queue, 0, sizeof(int), st));
+    if (g.LH == 16 && g.T == 2) stream_launch<16, 2>(k, A, st);
+    else if (g.LH == 8 && g.T == 1) stream_launch<8, 1>(k, A, st);
+    else if (g.T == 1) stream_launch<0, 1>(k, A, st);
+    else if (g.T == 2) stream_launch<0, 2>(k, A, st);
+    else stream_launch<0, 4>(k, A, st);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
 static int check_inagg(const gatmi_graph *g, const gatmi_inagg *a, InGeo *geo) {
     GATMI_REQUIRE(g && a, "null graph/layer descriptor");
     GATMI_REQUIRE(make_in_geo(a->shape, geo),
@@ -485,7 +853,8 @@ static int check_inagg(const gatmi_graph *g, const gatmi_inagg *a, InGeo *geo) {
     GATMI_REQUIRE(a->mask_mode != GATMI_MASK_BYTES || a->mask, "mask_mode BYTES needs a mask");
     GATMI_REQUIRE(a->dropout_p >= 0.f && a->dropout_p <= 1.f, "dropout_p %f outside [0,1]",
                   a->dropout_p);
-    GATMI_REQUIRE(a->x && a->weight && a->att_src && a->att_dst, "null x/weight/att_src/att_dst");
+    GATMI_REQUIRE(a->xs && a->a_dst && a->weight && a->att_src && a->att_dst,
+                  "null xs/a_dst/weight/att_src/att_dst");
     return GATMI_OK;
 }
 
@@ -500,6 +869,7 @@ static void fill_in_args(InArgs &A, const gatmi_graph *g, const gatmi_inagg *a, 
     A.seg_len = g->seg_len;
     A.H = a->shape.heads;
     A.Fp = geo.Fp;
+    A.Fs = geo.Fs;
     A.lph = geo.lph;
     A.lh_log = geo.lh_log;
     A.dst_off = g->dst_offset;
@@ -510,38 +880,9 @@ static void fill_in_args(InArgs &A, const gatmi_graph *g, const gatmi_inagg *a, 
     A.mask_mode = a->mask_mode;
     A.mask = a->mask;
     A.seed = a->seed;
-}
-
-// ws, wd and (when F % 4 != 0) the padded copy of x: the start of both workspaces
-struct InCommonWs {
-    float *wsd, *xp;
-};
-static InCommonWs carve_common(Carver &cv, const gatmi_graph *g, const gatmi_shape *s,
-                               const InGeo &geo) {
-    InCommonWs w;
-    w.wsd = cv.take<float>((size_t)2 * geo.HF);
-    w.xp = (s->in_features & 3) ? cv.take<float>((size_t)g->num_src * geo.Fp) : nullptr;
-    return w;
-}
-
-static int prepare_common(const InCommonWs &w, const gatmi_graph *g, const gatmi_inagg *a,
-                          const InGeo &geo, InArgs &A, hipStream_t st) {
-    const int H = a->shape.heads, C = a->shape.channels, F = a->shape.in_features;
-    ProfScope ps("inagg_prep", st);
-    hipLaunchKernelGGL(inagg_wsd_kernel, dim3((2 * geo.HF + 255) / 256), dim3(256), 0, st, a->weight,
-                       a->att_src, a->att_dst, H, C, F, geo.Fp, w.wsd);
-    GATMI_HIP(hipGetLastError());
-    A.wsd = w.wsd;
-    A.xp = a->x;
-    if (w.xp && g->num_src > 0) {
-        const long long tot = (long long)g->num_src * geo.Fp;
-        const int blocks = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
-        hipLaunchKernelGGL(inagg_pad_x_kernel, dim3(blocks), dim3(256), 0, st, a->x, w.xp,
-                           (long long)g->num_src, F, geo.Fp);
-        GATMI_HIP(hipGetLastError());
-        A.xp = w.xp;
-    }
-    return GATMI_OK;
+    A.xs = a->xs;
+    A.a_dst = a->a_dst;
+    A.E = g->num_edges;
 }
 
 constexpr int kGsumBlocks = 1024;
@@ -570,15 +911,70 @@ extern "C" size_t gatmi_inagg_z_floats(const gatmi_shape *s) {
     return (size_t)geo.HF;
 }
 
+extern "C" size_t gatmi_inagg_xs_floats(const gatmi_shape *s) {
+    InGeo geo;
+    if (!s || !make_in_geo(*s, &geo)) return 0;
+    return (size_t)geo.Fs;
+}
+
+extern "C" size_t gatmi_inagg_pack_workspace_bytes(const gatmi_shape *s) {
+    InGeo geo;
+    if (!s || !make_in_geo(*s, &geo)) return 0;
+    return align_up((size_t)2 * geo.HF * 4) + 256;
+}
+
+extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const float *weight,
+                                const float *att_src, const float *att_dst, float *xs, float *a_dst,
+                                void *ws, size_t ws_bytes, void *stream) {
+    GATMI_REQUIRE(s && x && weight && att_src && att_dst && xs && a_dst, "null argument");
+    InGeo geo;
+    GATMI_REQUIRE(make_in_geo(*s, &geo), "input-side aggregation does not cover F=%d H=%d",
+                  s->in_features, s->heads);
+    GATMI_REQUIRE(s->num_nodes >= 0, "negative row count");
+    if (ws_bytes < gatmi_inagg_pack_workspace_bytes(s)) {
+        set_error("inagg_pack workspace too small: %zu < %zu", ws_bytes,
+                  gatmi_inagg_pack_workspace_bytes(s));
+        return GATMI_ERR_WS;
+    }
+    if (s->num_nodes == 0) return GATMI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *wsd = static_cast<float *>(ws);
+    const int H = s->heads, C = s->channels, F = s->in_features;
+    ProfScope ps("inagg_pack", st);
+    hipLaunchKernelGGL(inagg_wsd_kernel, dim3((2 * geo.HF + 255) / 256), dim3(256), 0, st, weight,
+                       att_src, att_dst, H, C, F, geo.Fp, wsd);
+    GATMI_HIP(hipGetLastError());
+    int gl = next_pow2(geo.lph);
+    if (gl > 64) gl = 64;
+    const int ks = (geo.lph + gl - 1) / gl;   // <= 4: lph <= 256 whenever make_in_geo accepts
+    GATMI_REQUIRE(ks <= 4, "in_features %d too wide to pack", F);
+    const long long rpw = 64 / gl;
+    long long blocks = (s->num_nodes + rpw * 4 - 1) / (rpw * 4);
+    if (blocks > 4096) blocks = 4096;
+    const int glog = ilog2(gl);
+    const long long n = s->num_nodes;
+    if (ks == 1)
+        hipLaunchKernelGGL(inagg_pack_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, wsd, n, F,
+                           geo.Fp, geo.Fs, H, glog, xs, a_dst);
+    else if (ks == 2)
+        hipLaunchKernelGGL(inagg_pack_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, wsd, n, F,
+                           geo.Fp, geo.Fs, H, glog, xs, a_dst);
+    else
+        hipLaunchKernelGGL(inagg_pack_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, wsd, n, F,
+                           geo.Fp, geo.Fs, H, glog, xs, a_dst);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
 extern "C" size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s) {
     InGeo geo;
     if (!g || !s || !make_in_geo(*s, &geo)) return 0;
     Carver cv(nullptr);
-    carve_common(cv, g, s, geo);
     const size_t slots = (size_t)g->plan.n_slots;
     cv.take<float>(slots * s->heads);
     cv.take<float>(slots * s->heads);
     cv.take<float>(slots * geo.HF);
+    cv.take<int>(64);   // chunk queue of the streaming kernel
     return cv.off + 256;
 }
 
@@ -596,19 +992,22 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
     const int N = g->num_dst, H = a->shape.heads, C = a->shape.channels, F = a->shape.in_features;
     if (N == 0) return GATMI_OK;
     Carver cv(ws);
-    const InCommonWs cw = carve_common(cv, g, &a->shape, geo);
     InArgs A;
     fill_in_args(A, g, a, geo);
-    if (int e = prepare_common(cw, g, a, geo, A, st)) return e;
     const size_t slots = (size_t)g->plan.n_slots;
     A.part_m = cv.take<float>(slots * H);
     A.part_s = cv.take<float>(slots * H);
     A.part_acc = cv.take<float>(slots * geo.HF);
+    A.queue = cv.take<int>(64);
     A.z = z;
     A.lse = lse;
     {
         ProfScope ps("inagg_fwd", st);
-        if (int e = in_launch_rows(IN_FWD, geo, A, in_grid(geo, A.n_items), st)) return e;
+        if (stream_ok(geo, H)) {
+            if (int e = stream_launch_rows(IN_FWD, geo, A, st)) return e;
+        } else if (int e = in_launch_rows(IN_FWD, geo, A, in_grid(geo, A.n_items), st)) {
+            return e;
+        }
     }
     if (g->plan.n_split_rows > 0) {
         ProfScope ps("inagg_fwd_merge", st);
@@ -635,7 +1034,6 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
 
 namespace {
 struct InBwdWs {
-    InCommonWs cw;
     float *q, *part_y, *dwsd, *slab, *gsum;
     int waves, nsplit;
     size_t bytes;
@@ -643,7 +1041,6 @@ struct InBwdWs {
 InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &geo, void *ws) {
     Carver cv(ws);
     InBwdWs w;
-    w.cw = carve_common(cv, g, s, geo);
     const size_t N = (size_t)g->num_dst;
     w.q = cv.take<float>(N * geo.HF);
     w.waves = in_grid(geo, g->plan.n_items) * 4;
@@ -680,7 +1077,6 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     const InBwdWs w = carve_in_bwd(g, &a->shape, geo, ws);
     InArgs A;
     fill_in_args(A, g, a, geo);
-    if (int e = prepare_common(w.cw, g, a, geo, A, st)) return e;
     if (N > 0) {
         // q[:, h, :] = g[:, h, :] W_h   (padded columns written as zeros)
         ProfScope ps("inagg_q_gemm", st);

@@ -63,17 +63,18 @@ class _GATConvInAggFn(torch.autograd.Function):
         att_d = att_dst.contiguous().view(-1)
         bias_c = None if bias is None else bias.contiguous()
         need_grad = any(ctx.needs_input_grad[1:5])
-        out, z, lse = ops.inagg_fwd(layout, cfg, x, weight, att_s, att_d, bias_c, need_grad)
+        xs, a_dst = ops.inagg_pack(x, weight, att_s, att_d, cfg.heads, cfg.channels)
+        out, z, lse = ops.inagg_fwd(layout, cfg, xs, a_dst, weight, att_s, att_d, bias_c, need_grad)
         if need_grad:
-            ctx.save_for_backward(x, weight, att_s, att_d, bias_c, z, lse)
+            ctx.save_for_backward(xs, a_dst, weight, att_s, att_d, bias_c, z, lse)
             ctx.layout, ctx.cfg, ctx.att_shape = layout, cfg, att_src.shape
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight, att_s, att_d, bias_c, z, lse = ctx.saved_tensors
-        d_w, d_as, d_ad, d_b = ops.inagg_bwd(ctx.layout, ctx.cfg, x, weight, att_s, att_d, bias_c,
-                                             z, lse, grad_out.contiguous())
+        xs, a_dst, weight, att_s, att_d, bias_c, z, lse = ctx.saved_tensors
+        d_w, d_as, d_ad, d_b = ops.inagg_bwd(ctx.layout, ctx.cfg, xs, a_dst, weight, att_s, att_d,
+                                             bias_c, z, lse, grad_out.contiguous())
         return None, d_w, d_as.view(ctx.att_shape), d_ad.view(ctx.att_shape), d_b, None, None
 
 

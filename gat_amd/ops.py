@@ -138,29 +138,51 @@ def inagg_supported(in_features: int, heads: int, channels: int) -> bool:
             and bool(_lib.lib().gatmi_inagg_supported(C.byref(shape))))
 
 
-def _inagg_args(cfg: AttnConfig, num_dst, x, weight, att_src, att_dst, bias):
+def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, heads: int,
+               channels: int) -> Tuple[Tensor, Tensor]:
+    """rows of x -> packed source rows xs [n, Fs] (x | a_src | pad) and a_dst [n, H]."""
+    lib, dev = _lib.lib(), x.device
+    n, f = x.shape
+    shape = _lib.Shape(n, f, heads, channels)
+    fs = int(lib.gatmi_inagg_xs_floats(C.byref(shape)))
+    if fs == 0:
+        raise RuntimeError(f"input-side aggregation does not cover F={f} H={heads}")
+    with torch.cuda.device(dev):
+        xs = torch.empty(n, fs, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
+        ws = _ws(lib.gatmi_inagg_pack_workspace_bytes(C.byref(shape)), dev)
+        _lib.check(lib.gatmi_inagg_pack(C.byref(shape), x.data_ptr(), weight.data_ptr(),
+                                        att_src.data_ptr(), att_dst.data_ptr(), xs.data_ptr(),
+                                        a_dst.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "gatmi_inagg_pack")
+    return xs, a_dst
+
+
+def _inagg_args(cfg: AttnConfig, num_dst, in_features, xs, a_dst, weight, att_src, att_dst, bias):
     a = _lib.InAgg()
-    a.shape = _lib.Shape(num_dst, x.size(1), cfg.heads, cfg.channels)
+    a.shape = _lib.Shape(num_dst, in_features, cfg.heads, cfg.channels)
     a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
     a.mask_mode, a.seed, a.mask = cfg.mask_mode, cfg.seed, _ptr(cfg.mask)
-    a.x, a.weight = x.data_ptr(), weight.data_ptr()
+    a.xs, a.a_dst, a.weight = xs.data_ptr(), a_dst.data_ptr(), weight.data_ptr()
     a.att_src, a.att_dst, a.bias = _ptr(att_src), _ptr(att_dst), _ptr(bias)
     return a
 
 
-def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, x: Tensor, weight: Tensor, att_src: Tensor,
-              att_dst: Tensor, bias: Optional[Tensor], need_lse: bool
+def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, weight: Tensor,
+              att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], need_lse: bool
               ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
-    """x [num_src, F] (all nodes) -> out [num_dst, H*C], z [num_dst, H*Fp], lse [num_dst, H]."""
-    lib, dev = _lib.lib(), x.device
+    """xs [num_src, Fs] (all nodes), a_dst [num_dst, H] -> out [num_dst, H*C], z [num_dst, H*Fp],
+    lse [num_dst, H]."""
+    lib, dev = _lib.lib(), xs.device
     n = layout.num_dst
-    if x.size(0) != layout.num_nodes:
-        raise ValueError(f"x has {x.size(0)} rows, the graph {layout.num_nodes} source nodes")
+    if xs.size(0) != layout.num_nodes or a_dst.size(0) != n:
+        raise ValueError(f"xs has {xs.size(0)} rows / a_dst {a_dst.size(0)}, the graph "
+                         f"{layout.num_nodes} sources / {n} destinations")
     with torch.cuda.device(dev):
-        a = _inagg_args(cfg, n, x, weight, att_src, att_dst, bias)
+        a = _inagg_args(cfg, n, weight.size(1), xs, a_dst, weight, att_src, att_dst, bias)
+        if int(lib.gatmi_inagg_xs_floats(C.byref(a.shape))) != xs.size(1):
+            raise ValueError("xs row width does not match this layer")
         zf = int(lib.gatmi_inagg_z_floats(C.byref(a.shape)))
-        if zf == 0:
-            raise RuntimeError(f"input-side aggregation does not cover F={x.size(1)} H={cfg.heads}")
         out = torch.empty(n, cfg.heads * cfg.channels, dtype=torch.float32, device=dev)
         z = torch.empty(n, zf, dtype=torch.float32, device=dev)
         lse = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev) if need_lse else None
@@ -171,12 +193,14 @@ def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, x: Tensor, weight: Tensor, a
     return out, z, lse
 
 
-def inagg_bwd(layout: GraphLayout, cfg: AttnConfig, x: Tensor, weight: Tensor, att_src: Tensor,
-              att_dst: Tensor, bias: Optional[Tensor], z: Tensor, lse: Tensor, grad_out: Tensor):
+def inagg_bwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, weight: Tensor,
+              att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], z: Tensor, lse: Tensor,
+              grad_out: Tensor):
     """-> d_weight, d_att_src, d_att_dst, d_bias (partial sums on a destination partition)."""
-    lib, dev = _lib.lib(), x.device
+    lib, dev = _lib.lib(), xs.device
     with torch.cuda.device(dev):
-        a = _inagg_args(cfg, layout.num_dst, x, weight, att_src, att_dst, bias)
+        a = _inagg_args(cfg, layout.num_dst, weight.size(1), xs, a_dst, weight, att_src, att_dst,
+                        bias)
         d_w = torch.empty_like(weight)
         d_as = torch.empty_like(att_src)
         d_ad = torch.empty_like(att_dst)

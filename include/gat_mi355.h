@@ -193,7 +193,24 @@ int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float *d_a_dst,
  *     out[i,h,:] = W_h (sum_e alpha~_e x_j) + bias_h,    a_src[j,h] = <x_j, W_h^T att_src_h>,
  * so every edge gathers an x row (F floats) instead of a projected row (H*C floats); the
  * backward runs on the destination CSR alone and yields the parameter gradients (there is
- * no d_x).  Results equal gatmi_project_fwd + gatmi_attn_fwd up to fp32 re-association. */
+ * no d_x).  Results equal gatmi_project_fwd + gatmi_attn_fwd up to fp32 re-association.
+ *
+ * Step 1, gatmi_inagg_pack: rows of x -> rows of the packed source table
+ *     xs[n] = x[n, 0..F) zero-padded to Fp = round_up(F,4) | a_src[n, 0..H) | zero pad
+ * (Fs = Fp + round_up(H,4) floats per row: the source logit rides at the end of the row an
+ * edge gathers anyway) and a_dst [n, H].  A destination partition packs its own rows and
+ * all-gathers xs; a_dst stays local.
+ * Step 2, gatmi_inagg_fwd / gatmi_inagg_bwd over the graph. */
+int gatmi_inagg_supported(const gatmi_shape *s); /* 1: H <= 32 and Fp/4 <= 4*64/next_pow2(H) */
+size_t gatmi_inagg_xs_floats(const gatmi_shape *s); /* Fs */
+size_t gatmi_inagg_z_floats(const gatmi_shape *s);  /* H * Fp */
+
+size_t gatmi_inagg_pack_workspace_bytes(const gatmi_shape *s);
+int gatmi_inagg_pack(const gatmi_shape *s /* num_nodes = rows to pack */, const float *x,
+                     const float *weight, const float *att_src, const float *att_dst,
+                     float *xs /* [rows, Fs] */, float *a_dst /* [rows, H] */,
+                     void *ws, size_t ws_bytes, void *stream);
+
 typedef struct gatmi_inagg {
     gatmi_shape shape;     /* num_nodes = destination rows                              */
     float negative_slope;
@@ -202,20 +219,16 @@ typedef struct gatmi_inagg {
     int32_t _pad;
     uint64_t seed;
     const uint8_t *mask;   /* GATMI_MASK_BYTES: [E', H] keep flags, dst-CSR order       */
-    const float *x;        /* [num_src, F] input rows (all nodes of the graph)          */
+    const float *xs;       /* [num_src, Fs] packed source rows (all nodes of the graph) */
+    const float *a_dst;    /* [num_dst, H]                                              */
     const float *weight;   /* [H*C, F]                                                  */
     const float *att_src;  /* [H*C]                                                     */
     const float *att_dst;  /* [H*C]                                                     */
     const float *bias;     /* [H*C] or NULL                                             */
 } gatmi_inagg;
 
-/* 1 when the kernels cover this (F, H): H <= 32 and round_up(F,4)/4 <= 4 * 64/next_pow2(H). */
-int gatmi_inagg_supported(const gatmi_shape *s);
-/* Floats per destination row of the aggregated-input table z: H * round_up(F, 4). */
-size_t gatmi_inagg_z_floats(const gatmi_shape *s);
-
-/*   -> out [num_dst, H*C],  z [num_dst, H*round_up(F,4)] (kept for the backward),
- *      lse [num_dst, H] (NULL when no backward follows)                                 */
+/*   -> out [num_dst, H*C],  z [num_dst, H*Fp] (the per-head aggregated inputs, kept for the
+ *      backward),  lse [num_dst, H] (NULL when no backward follows)                     */
 size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
 int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float *out, float *z, float *lse,
                     void *ws, size_t ws_bytes, void *stream);
