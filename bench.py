@@ -93,9 +93,12 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.425)  # run.py:21, attention dropout on
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "h", "x"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "h", "x", "xs", "as"],
                     help="N>1: what the destination partition all-gathers (gat_amd/dist.py)")
     args = ap.parse_args()
+    if os.environ.get("GAT_HANG_DUMP"):      # debugging aid: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GAT_HANG_DUMP"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -12,8 +12,17 @@ the in-edges of those destinations:
   backward  fused backward over the own edges -> partial d_h for ALL sources ->
             REDUCE-SCATTER d_h (adjoint of the all-gather) -> + d_a_dst att_dst on own rows
             -> own d_x and partial d_W -> ALL-REDUCE of d_W, d_att_src, d_att_dst, d_bias
-  (exchange="x", chosen when F < Dp: all-gather the input rows instead and project them on
-  every rank; see _PartitionedFn)
+  (exchange="x": all-gather the input rows instead and project them on every rank; see
+  _PartitionedFn)
+
+When the layer's input needs no gradient and is narrower than its output (the reference's
+conv1: x is `data.x`), the input-side aggregation kernels run instead (gat_amd/csrc/inagg.hip,
+_PartitionedInAggFn): every edge gathers a packed source row  x_j | a_src[j]  and the backward
+needs no exchange at all besides the parameter all-reduce.
+  exchange="xs"  pack own rows -> ALL-GATHER the packed rows (Fs floats per node) every step
+  exchange="as"  the x part of the packed table is static data: it is all-gathered once per
+                 x tensor and kept; every step all-gathers only the projected source logits
+                 a_src [N, H] (they change with the weights) into the table's last columns
 
 Blocks are equal (B = ceil(N / P) nodes, the last ones shorter or empty) so the
 collectives are the plain equal-shard forms.  The compute steps go through a small backend
@@ -138,6 +147,28 @@ class HipBackend:
         from . import ops
         return ops.project_bwd(x, w, d_hp.contiguous(), cfg.heads, cfg.channels, need_dx)
 
+    # input-side aggregation (x without gradient, F < H*Cp)
+    def inagg_supported(self, f, cfg):
+        from . import ops
+        return ops.inagg_supported(f, cfg.heads, cfg.channels)
+
+    def inagg_logit_columns(self, f, cfg):
+        """(first, count): where a_src sits in a packed row."""
+        fp = (f + 3) // 4 * 4
+        return fp, (cfg.heads + 3) // 4 * 4
+
+    def inagg_pack(self, x, w, att_s, att_d, cfg):
+        from . import ops
+        return ops.inagg_pack(x, w, att_s, att_d, cfg.heads, cfg.channels)
+
+    def inagg_fwd(self, layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, need_lse):
+        from . import ops
+        return ops.inagg_fwd(layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, need_lse)
+
+    def inagg_bwd(self, layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, z, lse, grad_out):
+        from . import ops
+        return ops.inagg_bwd(layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, z, lse, grad_out)
+
 
 def _pad_rows(t: Tensor, rows: int) -> Tensor:
     if t.size(0) == rows:
@@ -202,6 +233,50 @@ class _PartitionedFn(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
+class _PartitionedInAggFn(torch.autograd.Function):
+    """Input-side aggregation on a destination partition.  `table` is the packed source table
+    of ALL nodes [padded_nodes, Fs]: exchange "xs" fills it by all-gathering the packed rows,
+    exchange "as" keeps its x columns from an earlier call (static data) and all-gathers only
+    the a_src columns.  The backward is local; the parameter gradients are all-reduced."""
+
+    @staticmethod
+    def forward(ctx, x_local, weight, att_src, att_dst, bias, part, layout, cfg, be, group,
+                exchange, cache):
+        x_local, weight = x_local.contiguous(), weight.contiguous()
+        att_s, att_d = att_src.contiguous().view(-1), att_dst.contiguous().view(-1)
+        bias_c = None if bias is None else bias.contiguous()
+        xs_local, a_dst = be.inagg_pack(x_local, weight, att_s, att_d, cfg)
+        if exchange == "xs":
+            table = all_gather_rows(_pad_rows(xs_local, part.block), part.world, group)
+        else:
+            c0, cn = be.inagg_logit_columns(x_local.size(1), cfg)
+            key = (x_local.data_ptr(), tuple(x_local.shape), x_local._version, part.world)
+            if cache.get("key") != key:       # first call for this x: replicate the rows once
+                cache["key"] = key
+                cache["table"] = all_gather_rows(_pad_rows(xs_local, part.block), part.world, group)
+            else:                             # later calls: only the logits travel
+                logits = all_gather_rows(_pad_rows(xs_local[:, c0:c0 + cn], part.block),
+                                         part.world, group)
+                cache["table"][:, c0:c0 + cn] = logits
+            table = cache["table"]
+        need_grad = any(ctx.needs_input_grad[1:5])
+        out, z, lse = be.inagg_fwd(layout, cfg, table, a_dst, weight, att_s, att_d, bias_c, need_grad)
+        if need_grad:
+            ctx.save_for_backward(table, a_dst, weight, att_s, att_d, bias_c, z, lse)
+            ctx.misc = (layout, cfg, be, group, att_src.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        table, a_dst, weight, att_s, att_d, bias_c, z, lse = ctx.saved_tensors
+        layout, cfg, be, group, att_shape = ctx.misc
+        d_w, d_as, d_ad, d_b = be.inagg_bwd(layout, cfg, table, a_dst, weight, att_s, att_d, bias_c,
+                                            z, lse, grad_out.contiguous())
+        all_reduce_many([d_w, d_as, d_ad, d_b], group)
+        return (None, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
+                None, None, None, None, None, None, None)
+
+
 class PartitionedGATConv(nn.Module):
     """GATConv (model.py:26,28,30) whose forward takes this rank's rows of x.  Parameters
     are replicated (same seed / broadcast by the caller); their gradients come back
@@ -220,10 +295,13 @@ class PartitionedGATConv(nn.Module):
         _glorot_(self.lin.weight), _glorot_(self.att_src), _glorot_(self.att_dst)
         self.backend = backend or HipBackend()
         self.group = group
-        if exchange == "auto":     # fewer columns on the wire wins
-            exchange = "x" if in_channels < heads * ((out_channels + 3) // 4 * 4) else "h"
+        # "auto": input-side aggregation with the static rows replicated once ("as") when the
+        # input carries no gradient and the kernels cover the shape, else all-gather h
+        if exchange not in ("auto", "h", "x", "xs", "as"):
+            raise ValueError(f"unknown exchange mode {exchange!r}")
         self.exchange = exchange
         self._layouts = {}
+        self._table_cache = {}
 
     def layout_for(self, edge_index: Tensor, part: Partition):
         key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, part.rank)
@@ -245,12 +323,39 @@ class PartitionedGATConv(nn.Module):
             seed = int(torch.empty((), dtype=torch.int64).random_().item()) + part.rank
         cfg = AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
                          mask_mode, seed, None)
+        mode = self.resolve_exchange(x_local, cfg)
+        if mode in ("xs", "as"):
+            return _PartitionedInAggFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
+                                             self.bias, part, layout, cfg, self.backend,
+                                             self.group, mode, self._table_cache)
         return _PartitionedFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
-                                    self.bias, part, layout, cfg, self.backend, self.group,
-                                    self.exchange)
+                                    self.bias, part, layout, cfg, self.backend, self.group, mode)
+
+    def resolve_exchange(self, x_local: Tensor, cfg) -> str:
+        x_grad = x_local.requires_grad and torch.is_grad_enabled()
+        can = not x_grad and self.backend.inagg_supported(self.in_channels, cfg)
+        if self.exchange == "auto":
+            if can:
+                return "as"
+            dp = self.heads * ((self.out_channels + 3) // 4 * 4)
+            return "x" if self.in_channels < dp else "h"   # fewer columns on the wire wins
+        if self.exchange in ("xs", "as") and not can:
+            raise RuntimeError(f"exchange={self.exchange!r} needs an input without gradient and a "
+                               "shape the input-side aggregation kernels cover")
+        return self.exchange
 
 
 # ------------------------------------------------------------------ bench.py --gpus N
+EXCHANGE_TEXT = {
+    "h": "all-gather(h) fwd, reduce-scatter(d_h) + all-reduce(param grads) bwd",
+    "x": "all-gather(x) + full projection fwd, all-reduce(param grads) bwd",
+    "xs": "input-side aggregation; all-gather(packed rows x|a_src) fwd every step, "
+          "all-reduce(param grads) bwd",
+    "as": "input-side aggregation; static x rows replicated once before the timed steps, "
+          "all-gather(a_src [N,H]) fwd every step, all-reduce(param grads) bwd",
+}
+
+
 def bench_partitioned(args, rank: int, world: int, dev) -> None:
     """One products-shaped layer, destination-partitioned over `world` GPUs; rank 0 prints
     bench.py's JSON line.  Every rank regenerates the same graph from the seed and keeps
@@ -272,6 +377,8 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     dist.all_reduce(edges)
     ep = int(edges.item())
     go = torch.randn(part.n_local, h * c, generator=g, device=dev)
+    from .ops import AttnConfig
+    mode = conv.resolve_exchange(x, AttnConfig(h, c))
 
     def step():
         conv.zero_grad(set_to_none=True)
@@ -301,11 +408,8 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                                       f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
                                       f"layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
                           "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
-                          "parallelism": (f"destination partition x{world}, exchange={conv.exchange}: "
-                                          + ("all-gather(x) fwd, all-reduce(param grads) bwd"
-                                             if conv.exchange == "x" else
-                                             "all-gather(h) fwd, reduce-scatter(d_h) + all-reduce(param grads) bwd")
-                                          + ", RCCL"),
+                          "parallelism": f"destination partition x{world}, exchange={mode}: "
+                                         + EXCHANGE_TEXT[mode] + f", {dist.get_backend()}",
                           "graph_layout_build_s": round(t_layout, 4)},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(res))

@@ -61,6 +61,49 @@ class OracleBackend:
         return d_hp.t() @ x, (d_hp @ w if need_dx else None)
 
 
+    # input-side aggregation stand-in: packed rows are x | a_src (no padding here)
+    def inagg_supported(self, f, cfg):
+        return True
+
+    def inagg_logit_columns(self, f, cfg):
+        return f, cfg.heads
+
+    def inagg_pack(self, x, w, att_s, att_d, cfg):
+        h_, c_ = cfg.heads, cfg.channels
+        hh = (x @ w.t()).view(-1, h_, c_)
+        a_src = (hh * att_s.view(1, h_, c_)).sum(-1)
+        a_dst = (hh * att_d.view(1, h_, c_)).sum(-1)
+        return torch.cat([x, a_src], dim=1), a_dst
+
+    def _inagg_out(self, layout, cfg, x_full, a_src, a_dst, w, bias):
+        h_, c_ = cfg.heads, cfg.channels
+        src, dst = layout["ei"][0], layout["ei"][1]
+        n_loc = layout["part"].n_local
+        z = torch.nn.functional.leaky_relu(a_src[src] + a_dst[dst], cfg.negative_slope)
+        alpha = O.segment_softmax(z, dst, n_loc)
+        agg = torch.zeros(n_loc, h_, x_full.size(1), dtype=x_full.dtype).index_add_(
+            0, dst, alpha.unsqueeze(-1) * x_full[src].unsqueeze(1))
+        out = torch.einsum("nhf,hcf->nhc", agg, w.view(h_, c_, -1)).reshape(n_loc, h_ * c_)
+        return out + bias if bias is not None else out
+
+    def inagg_fwd(self, layout, cfg, table, a_dst, w, att_s, att_d, bias, need_lse):
+        f = w.size(1)
+        with torch.no_grad():
+            out = self._inagg_out(layout, cfg, table[:, :f], table[:, f:f + cfg.heads], a_dst, w, bias)
+        return out, torch.zeros(1), torch.zeros(1)
+
+    def inagg_bwd(self, layout, cfg, table, a_dst, w, att_s, att_d, bias, z, lse, grad_out):
+        part, f, h_, c_ = layout["part"], w.size(1), cfg.heads, cfg.channels
+        x_full = table[:, :f]
+        wl, asl, adl, bl = [t.detach().clone().requires_grad_(True) for t in (w, att_s, att_d, bias)]
+        with torch.enable_grad():   # logits recomputed from the leaves so that d_W sees them
+            hh = (x_full @ wl.t()).view(-1, h_, c_)
+            a_src = (hh * asl.view(1, h_, c_)).sum(-1)
+            a_d = (hh[part.lo:part.hi] * adl.view(1, h_, c_)).sum(-1)
+            self._inagg_out(layout, cfg, x_full, a_src, a_d, wl, bl).backward(grad_out)
+        return wl.grad, asl.grad, adl.grad, bl.grad
+
+
 def _worker(rank, world, port, n, gname, exchange, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,13 +117,21 @@ def _worker(rank, world, port, n, gname, exchange, q):
         conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend(), exchange=exchange).double().eval()
         with torch.no_grad():
             conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
-        xl = x[part.lo:part.hi].clone().requires_grad_(True)
-        out = conv(xl, ei, n_)
-        out.backward(go[part.lo:part.hi])
+        inagg = exchange in ("xs", "as")
+        xl = x[part.lo:part.hi].clone().requires_grad_(not inagg)
+        steps = 2 if exchange == "as" else 1     # second step: cached rows, fresh logits
+        for step in range(steps):
+            conv.zero_grad()
+            if step == 1:                         # the weights moved: a_src must be re-gathered
+                with torch.no_grad():
+                    w = w * 1.25; conv.lin.weight.copy_(w)
+            out = conv(xl, ei, n_)
+            out.backward(go[part.lo:part.hi])
         ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
         tol = dict(rtol=1e-9, atol=1e-10)
         torch.testing.assert_close(out.detach(), ref_out[part.lo:part.hi], **tol)
-        torch.testing.assert_close(xl.grad, ref_g["x"][part.lo:part.hi], **tol)
+        if not inagg:
+            torch.testing.assert_close(xl.grad, ref_g["x"][part.lo:part.hi], **tol)
         torch.testing.assert_close(conv.lin.weight.grad, ref_g["weight"], **tol)
         torch.testing.assert_close(conv.att_src.grad, ref_g["att_src"], **tol)
         torch.testing.assert_close(conv.att_dst.grad, ref_g["att_dst"], **tol)
@@ -108,7 +159,9 @@ def _run(world, n, gname, exchange, port):
 
 @pytest.mark.parametrize("world,n,gname,exchange,port", [
     (2, 50, None, "h", 29611), (2, 51, None, "x", 29612), (2, None, "star", "h", 29613),
-    (3, 7, None, "h", 29614), (2, None, "star", "x", 29615), (3, 7, None, "x", 29616)])
+    (3, 7, None, "h", 29614), (2, None, "star", "x", 29615), (3, 7, None, "x", 29616),
+    (2, 50, None, "xs", 29617), (2, 51, None, "as", 29618), (3, 7, None, "as", 29619),
+    (2, None, "star", "as", 29620), (3, None, "star", "xs", 29621)])
 def test_partitioned_layer_equals_single_process(world, n, gname, exchange, port):
     _run(world, n, gname, exchange, port)
 

@@ -473,6 +473,42 @@ def test_partition_kernels_match_oracle(cuda, gname, sname, world):
     close(d_b, ref_g["bias"], "d_bias")
 
 
+@pytest.mark.parametrize("gname,sname,world", [("multigraph", "conv1_h30", 2), ("star", "products_l1", 3),
+                                               ("hub_source", "three_heads", 2), ("knn", "arxiv_l1", 4),
+                                               ("multigraph", "in_odd", 3)])
+def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world):
+    """Input-side aggregation in rectangular mode (what a rank of the multi-GPU layer runs):
+    every rank packs its own rows, the packed table is their concatenation (the all-gather),
+    the parameter gradients are the sum over ranks (the all-reduce)."""
+    from gat_amd import ops
+    from gat_amd.dist import HipBackend, Partition, local_edges
+    ei, n = cases.GRAPHS[gname]()
+    f, h, c = cases.SHAPES[sname]
+    x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c)
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    be = HipBackend(seg_len=64)
+    cfg = ops.AttnConfig(h, c)
+    xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
+    asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
+    parts = [Partition(n, world, r) for r in range(world)]
+    packed = [be.inagg_pack(xd[p.lo:p.hi].contiguous(), wd, asd, add_, cfg) for p in parts]
+    table = torch.cat([torch.cat([xs, xs.new_zeros(p.block - p.n_local, xs.size(1))])
+                       for p, (xs, _) in zip(parts, packed)])
+    outs, tot = [], None
+    for p, (_, a_dst) in zip(parts, packed):
+        lay = be.build_layout(local_edges(ei.to(cuda), p), p)
+        out, z, lse = be.inagg_fwd(lay, cfg, table, a_dst, wd, asd, add_, bd, True)
+        outs.append(out)
+        g = be.inagg_bwd(lay, cfg, table, a_dst, wd, asd, add_, bd, z, lse, god[p.lo:p.hi].contiguous())
+        tot = list(g) if tot is None else [a + b_ for a, b_ in zip(tot, g)]
+    close(torch.cat(outs), ref_out, "out")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    close(tot[0], ref_g["weight"], "d_weight")
+    close(tot[1], ref_g["att_src"], "d_att_src", floor=summand)
+    close(tot[2], ref_g["att_dst"], "d_att_dst", floor=summand)
+    close(tot[3], ref_g["bias"], "d_bias")
+
+
 # ------------------------------------------------------------------ randomized sweep
 def test_random_shapes_and_graphs(cuda):
     """40 seeded random (graph, shape, dropout, seg_len) draws, including heads that are not a
