@@ -88,6 +88,7 @@ struct GemmBatch {
     long long sA, sB, sC, sSplit, sBias;
     const float *bias;
     int nsplit, n_store;
+    float *asum;   // k-major A only: [batch * nsplit + split][M] column sums of A (or NULL)
 };
 // C[batch][split] (M x n_store, row stride ldc) = A (M x K) * B (K x Nn) over this split's K range.
 //   a_kmajor: A[k * lda + m] else A[m * lda + k];   b_kmajor: B[k * ldb + n] else B[n * ldb + k]
@@ -99,6 +100,7 @@ struct GemmDesc {
     int M, Nn, K, n_store, nbatch, nsplit;
     const float *bias; long long sBias;
     AFix fix;
+    float *asum;   // see GemmBatch
 };
 int launch_gemm(const GemmDesc &d, hipStream_t st);
 

@@ -598,71 +598,67 @@ template <int KS>
 __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const float *wsd, long long n,
                                                          int F, int Fp, int Fs, int H, int glog,
                                                          float *xs, float *a_dst) {
+    constexpr int UN = KS == 1 ? 4 : (KS == 2 ? 2 : 1);   // row groups in flight per wave
+    extern __shared__ float s_wsd[];                      // ws | wd, [2][H*Fp]
     const int lane = threadIdx.x & 63, gl = 1 << glog, sl = lane & (gl - 1), rsub = lane >> glog;
     const int rpw = 64 >> glog, lph = Fp >> 2, HF = H * Fp;
+    for (int i = threadIdx.x; i < 2 * HF; i += 256) s_wsd[i] = wsd[i];
+    __syncthreads();
     const bool vec = (F & 3) == 0;
     const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6), nwaves = gridDim.x * 4ll;
-    for (long long row0 = wave * rpw; row0 < n; row0 += nwaves * rpw) {
-        const long long row = row0 + rsub;
-        const bool on = row < n;
-        f4 xv[KS];
+    for (long long row0 = wave * rpw * UN; row0 < n; row0 += nwaves * rpw * UN) {
+        f4 xv[UN][KS];
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const int sub = sl + k * gl;
-            xv[k] = zero4();
-            if (on && sub < lph) {
-                const float *src = x + row * F + sub * 4;
-                if (vec) {
-                    xv[k] = ldv4(src);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (sub * 4 + c < F) xv[k][c] = src[c];
-                }
-                stv4(xs + row * Fs + sub * 4, xv[k]);
-            }
-        }
-        for (int h = 0; h < H; ++h) {
-            f2 ds = {0.f, 0.f}, dd = {0.f, 0.f};
+        for (int u = 0; u < UN; ++u) {
+            const long long row = row0 + u * rpw + rsub;
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
                 const int sub = sl + k * gl;
-                if (sub < lph) {
-                    pk_dot4(ds, xv[k], ldv4(wsd + h * Fp + sub * 4));
-                    pk_dot4(dd, xv[k], ldv4(wsd + HF + h * Fp + sub * 4));
+                xv[u][k] = zero4();
+                if (row < n && sub < lph) {
+                    const float *src = x + row * F + sub * 4;
+                    if (vec) {
+                        xv[u][k] = ldv4(src);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (sub * 4 + c < F) xv[u][k][c] = src[c];
+                    }
                 }
             }
-            float a = ds.x + ds.y, d = dd.x + dd.y;
-            for (int o = 1; o < gl; o <<= 1) {
-                a += __shfl_xor(a, o, 64);
-                d += __shfl_xor(d, o, 64);
-            }
-            if (on && sl == 0) {
-                xs[row * Fs + Fp + h] = a;
-                a_dst[row * H + h] = d;
-            }
         }
-        if (on && sl == 0)
-            for (int h = H; h < Fs - Fp; ++h) xs[row * Fs + Fp + h] = 0.f;
-    }
-}
-
-// partial[b][col] = sum over block b's stripe of rows of g[row][col]   (d_bias, stage 1)
-__global__ __launch_bounds__(256) void inagg_gsum_kernel(const float *g, long long n, int D,
-                                                         float *partial) {
-    const long long per = (n + gridDim.x - 1) / gridDim.x;
-    const long long r0 = blockIdx.x * per, r1 = min(n, r0 + per);
-    for (int col = threadIdx.x; col < D; col += 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        long long r = r0;
-        for (; r + 3 < r1; r += 4) {
-            s0 += g[r * D + col];
-            s1 += g[(r + 1) * D + col];
-            s2 += g[(r + 2) * D + col];
-            s3 += g[(r + 3) * D + col];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long row = row0 + u * rpw + rsub;
+            const bool on = row < n;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int sub = sl + k * gl;
+                if (on && sub < lph) stv4(xs + row * Fs + sub * 4, xv[u][k]);
+            }
+            for (int h = 0; h < H; ++h) {
+                f2 ds = {0.f, 0.f}, dd = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    const int sub = sl + k * gl;
+                    if (sub < lph) {
+                        pk_dot4(ds, xv[u][k], ldv4(s_wsd + h * Fp + sub * 4));
+                        pk_dot4(dd, xv[u][k], ldv4(s_wsd + HF + h * Fp + sub * 4));
+                    }
+                }
+                float a = ds.x + ds.y, d = dd.x + dd.y;
+                for (int o = 1; o < gl; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    d += __shfl_xor(d, o, 64);
+                }
+                if (on && sl == 0) {
+                    xs[row * Fs + Fp + h] = a;
+                    a_dst[row * H + h] = d;
+                }
+            }
+            if (on && sl == 0)
+                for (int h = H; h < Fs - Fp; ++h) xs[row * Fs + Fp + h] = 0.f;
         }
-        for (; r < r1; ++r) s0 += g[r * D + col];
-        partial[(size_t)blockIdx.x * D + col] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -700,8 +696,8 @@ __global__ __launch_bounds__(256) void inagg_sum_rows_kernel(SumJob j0, SumJob j
 // d_W = sum_split slab + att_src (x) d_ws + att_dst (x) d_wd;  d_att_k = W d_w{s,d}
 __global__ __launch_bounds__(256) void inagg_finalize_kernel(
     const float *slab, int nsplit, int H, int C, int F, int Fp, const float *w,
-    const float *att_src, const float *att_dst, const float *dwsd, float *d_w, float *d_att_src,
-    float *d_att_dst) {
+    const float *att_src, const float *att_dst, const float *dwsd, const float *gsum /* [H][nsplit][C] */,
+    float *d_w, float *d_att_src, float *d_att_dst, float *d_bias) {
     const long long tot = (long long)H * C * F;
     const float *dws = dwsd, *dwd = dwsd + (size_t)H * Fp;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < tot; i += gridDim.x * 256ll) {
@@ -729,6 +725,21 @@ __global__ __launch_bounds__(256) void inagg_finalize_kernel(
         float *dst = k == 0 ? d_att_src : d_att_dst;
         if (dst) dst[hc] = s;
     }
+    if (d_bias)   // column sums of grad_out, collected by the d_W GEMM while it staged them
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HC; i += gridDim.x * 256) {
+            const int h = i / C, c = i % C;
+            const float *src = gsum + (size_t)h * nsplit * C + c;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int z = 0;
+            for (; z + 3 < nsplit; z += 4) {
+                s0 += src[(size_t)z * C];
+                s1 += src[(size_t)(z + 1) * C];
+                s2 += src[(size_t)(z + 2) * C];
+                s3 += src[(size_t)(z + 3) * C];
+            }
+            for (; z < nsplit; ++z) s0 += src[(size_t)z * C];
+            d_bias[i] = (s0 + s1) + (s2 + s3);
+        }
 }
 
 // ---------------------------------------------------------------------------------
@@ -885,8 +896,6 @@ static void fill_in_args(InArgs &A, const gatmi_graph *g, const gatmi_inagg *a, 
     A.E = g->num_edges;
 }
 
-constexpr int kGsumBlocks = 1024;
-
 static int dw_splits(int N, int H, int C, int F) {
     const int tiles = ((C + 127) / 128) * ((F + 127) / 128) * H;
     int want = 1024 / tiles;
@@ -950,17 +959,20 @@ extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const floa
     GATMI_REQUIRE(ks <= 4, "in_features %d too wide to pack", F);
     const long long rpw = 64 / gl;
     long long blocks = (s->num_nodes + rpw * 4 - 1) / (rpw * 4);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     const int glog = ilog2(gl);
     const long long n = s->num_nodes;
     if (ks == 1)
-        hipLaunchKernelGGL(inagg_pack_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, wsd, n, F,
+        hipLaunchKernelGGL(inagg_pack_kernel<1>, dim3((unsigned)blocks), dim3(256),
+                           (size_t)2 * geo.HF * sizeof(float), st, x, wsd, n, F,
                            geo.Fp, geo.Fs, H, glog, xs, a_dst);
     else if (ks == 2)
-        hipLaunchKernelGGL(inagg_pack_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, wsd, n, F,
+        hipLaunchKernelGGL(inagg_pack_kernel<2>, dim3((unsigned)blocks), dim3(256),
+                           (size_t)2 * geo.HF * sizeof(float), st, x, wsd, n, F,
                            geo.Fp, geo.Fs, H, glog, xs, a_dst);
     else
-        hipLaunchKernelGGL(inagg_pack_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, wsd, n, F,
+        hipLaunchKernelGGL(inagg_pack_kernel<4>, dim3((unsigned)blocks), dim3(256),
+                           (size_t)2 * geo.HF * sizeof(float), st, x, wsd, n, F,
                            geo.Fp, geo.Fs, H, glog, xs, a_dst);
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
@@ -1048,7 +1060,7 @@ InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &ge
     w.dwsd = cv.take<float>((size_t)2 * geo.HF);
     w.nsplit = dw_splits(g->num_dst, s->heads, s->channels, s->in_features);
     w.slab = cv.take<float>((size_t)w.nsplit * s->heads * s->channels * s->in_features);
-    w.gsum = cv.take<float>((size_t)kGsumBlocks * s->heads * s->channels);
+    w.gsum = cv.take<float>((size_t)w.nsplit * s->heads * s->channels);
     w.bytes = cv.off + 256;
     return w;
 }
@@ -1104,20 +1116,12 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
             return e;
         }
     }
-    const int gblocks = N < kGsumBlocks ? (N > 0 ? N : 1) : kGsumBlocks;
     {
         ProfScope ps("inagg_colsums", st);
-        if (N > 0 && d_bias) {
-            hipLaunchKernelGGL(inagg_gsum_kernel, dim3(gblocks), dim3(256), 0, st, grad_out,
-                               (long long)N, H * C, w.gsum);
-            GATMI_HIP(hipGetLastError());
-        }
         SumJob j0{w.part_y, w.dwsd, w.waves, 2 * geo.HF, geo.HF};
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, w.waves, 2 * geo.HF, geo.HF};
-        SumJob j2{w.gsum, d_bias, N > 0 ? gblocks : 0, H * C, H * C};
-        const int widest = geo.HF > H * C ? geo.HF : H * C;
-        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((widest + 15) / 16, 3), dim3(256), 0, st, j0,
-                           j1, j2);
+        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0,
+                           j1, j1);
         GATMI_HIP(hipGetLastError());
     }
     {
@@ -1132,13 +1136,14 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
             d.M = C; d.Nn = F; d.K = N; d.n_store = F; d.nbatch = H; d.nsplit = w.nsplit;
             d.bias = nullptr; d.sBias = 0;
             d.fix = AFix{nullptr, nullptr, 1, 1};
+            d.asum = d_bias ? w.gsum : nullptr;   // [h][split][C]: d_bias rides on the staging of g
             if (int e = launch_gemm(d, st)) return e;
         }
         const long long tot = (long long)H * C * F;
         const int blocks = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
         hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab,
                            N > 0 ? w.nsplit : 0, H, C, F, geo.Fp, a->weight, a->att_src, a->att_dst,
-                           w.dwsd, d_weight, d_att_src, d_att_dst);
+                           w.dwsd, w.gsum, d_weight, d_att_src, d_att_dst, d_bias);
         GATMI_HIP(hipGetLastError());
     }
     return GATMI_OK;

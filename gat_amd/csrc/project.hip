@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 
     // Global -> registers for one K-tile (issued one tile ahead of its use), registers ->
     // LDS, MFMA over the tile.
+    float asum = 0.f;               // k-major A: sum of the staged column (gb.asum), for d_bias
     float ra[EA], rb[EB], rd[EA];   // rd: d_a_dst of the element's node (AFix), applied at LDS-store
     // time so the fetched tile stays in flight during the MFMA loop
     // AFix, k-major A (d_weight): this thread's column m0 + tid % BM never changes
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
             const int gk = k0 + k;
             const bool ok = gm < M && gk < kend;
             ra[i] = ok ? (A_KMAJOR ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
+            if (A_KMAJOR) asum += ra[i];
             if (fix.da_dst) {
                 const long long node = A_KMAJOR ? gk : gm;   // row of the d_h table
                 rd[i] = ok ? fix.da_dst[node * fix.H + fix_head] : 0.f;
@@ -129,6 +131,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (A_KMAJOR && gb.asum && blockIdx.y == 0) {
+        // column sums of this block's A slice: thread tid staged column tid % BM only
+        __shared__ float red[256];
+        red[tid] = asum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < M) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 256 / BM; ++q) s += red[tid + q * BM];
+            gb.asum[(size_t)blockIdx.z * M + m0 + tid] = s;
         }
     }
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -247,7 +261,7 @@ template <bool AK, bool BK_, int BM, int BN>
 static void launch_tile(const GemmDesc &d, int kps, hipStream_t st) {
     dim3 grid((d.M + BM - 1) / BM, (d.n_store + BN - 1) / BN,
               d.nsplit * d.nbatch);
-    GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, d.nsplit, d.n_store};
+    GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, d.nsplit, d.n_store, d.asum};
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, BM, BN>), grid, dim3(256), 0, st, d.A, d.lda, d.B,
                        d.ldb, d.C, d.ldc, d.M, d.Nn, d.K, kps, d.fix, gb);
 }
