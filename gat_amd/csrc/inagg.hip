@@ -21,7 +21,7 @@
 // consecutive lanes of a head hold T float4 of the x row each (sub = sl + t*LH), every head
 // group reads the same row.  Per-head dots are butterflies over LH lanes.
 #ifndef GATMI_INAGG_U2
-#define GATMI_INAGG_U2 4
+#define GATMI_INAGG_U2 2
 #endif
 #include "attn_device.h"
 #include "common.h"
@@ -97,6 +97,7 @@ struct InArgs {
     float *part_y;       // [waves][2][H*Fp]
     // streaming kernels (LDS-DMA ring): chunk queue
     int *queue;
+    const int *chunk_item;   // [n_chunks + 1]
     int n_chunks, E;
 };
 
@@ -226,8 +227,11 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
 // (global_load_lds_dwordx4, one copy per row, no VGPRs) through a per-wave ring of 1-KiB
 // slots; the head groups read their pieces back with ds_read_b128.
 //
-//   chunk     kChunkItems consecutive work items, claimed from an atomic queue; their edges
-//             are one contiguous range [cb, ce) of the CSR
+//   chunk     the work items that begin inside one bucket of kChunkEdges consecutive CSR
+//             edges (table built per launch by inagg_chunk_table_kernel), claimed from an
+//             atomic queue and walked in groups of <= kChunkItems items; a group's edges
+//             are one contiguous range [cb, ce) of the CSR.  Bucketing by edges bounds the
+//             serial work of a wave (a hub's 512-edge segments are 1-2 per chunk)
 //   producer  walks that range: one DMA instruction (a "stage") moves rpi = 64 / (Fs/4) rows,
 //             lane (er, ep) -> piece ep of the row of edge pe + er; stages restart at item
 //             boundaries.  col indices come from 64-entry windows DMA'd into LDS one window
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
 #ifndef GATMI_RING
 #define GATMI_RING 4
 #endif
-constexpr int kChunkItems = 16;
+constexpr int kChunkItems = 32;       // items per group (lane-parallel metadata: < 64)
+constexpr int kChunkEdgesLog = 9;     // bucket of 512 edges
 constexpr int kColWin = 4;   // col windows in the LDS ring (power of two, >= 4)
 constexpr int kStreamMaxHeads = 8;
 
@@ -302,13 +307,28 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
     if (lane == 0) k = atomicAdd(A.queue, 1);                                             \
     k = __builtin_amdgcn_readfirstlane(k);                                                \
     if (k >= A.n_chunks) break;                                                           \
-    const int i0 = k * CH, ni = min(CH, A.n_items - i0);                                  \
+    const int ck0 = __builtin_amdgcn_readfirstlane(A.chunk_item[k]);                      \
+    const int ck1 = __builtin_amdgcn_readfirstlane(A.chunk_item[k + 1]);
+
+#define STREAM_GROUP_META                                                                 \
+    const int ni = min(CH, ck1 - i0);                                                     \
     const int il = i0 + lane;                                                             \
     const int vbeg = lane <= ni ? (il < A.n_items ? A.item_beg[il] : A.E) : 0;            \
     const int vrow = lane < ni ? A.item_row[il] : 0;                                      \
     const int vslot = lane < ni ? A.item_slot[il] : -1;                                   \
     const int cb = __builtin_amdgcn_readlane(vbeg, 0);                                    \
     const int ce = __builtin_amdgcn_readlane(vbeg, ni);
+
+// chunk_item[k] = first work item that begins at or after edge k << kChunkEdgesLog
+// (chunk_item[n_chunks] = n_items); items are in CSR order, so a chunk is a contiguous range.
+__global__ void inagg_chunk_table_kernel(const int *item_beg, int n_items, int n_chunks,
+                                         int *chunk_item) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n_items; i += gridDim.x * blockDim.x) {
+        const int b = i < n_items ? item_beg[i] >> kChunkEdgesLog : n_chunks;
+        const int bp = i > 0 ? item_beg[i - 1] >> kChunkEdgesLog : -1;
+        for (int k = bp + 1; k <= b; ++k) chunk_item[k] = i;
+    }
+}
 
 template <int LH_T, int T>
 __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
@@ -317,6 +337,8 @@ __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
     float *adl = s_adst[wv];
     for (;;) {
         STREAM_CLAIM_CHUNK
+        for (int i0 = ck0; i0 < ck1; i0 += CH) {
+        STREAM_GROUP_META
         for (int t0 = 0; t0 < ni * A.H; t0 += 64) {
             const int t = t0 + lane;
             const int itx = min(t / A.H, ni - 1);
@@ -449,6 +471,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
             }
         }
         wait_lds();
+        }
     }
 }
 
@@ -807,9 +830,15 @@ static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, h
 
 // Streaming (LDS-DMA) kernels: one row per wave (G == 64), a packed row fits one DMA
 // instruction (Fs/4 <= 64 lanes), per-chunk logit tables sized for <= kStreamMaxHeads heads.
-static bool stream_ok(const InGeo &g, int H) {
-    static const bool off = getenv("GATMI_NO_STREAM") != nullptr;   // A/B switch for benchmarks
-    return !off && g.G == 64 && g.Fs / 4 <= 64 && H <= kStreamMaxHeads;
+// They pay when the packed table is far larger than the 256 MiB Infinity Cache (rows come
+// from HBM and bytes in flight decide); a cache-resident table is served faster by the
+// register pipeline (lower per-edge overhead).  GATMI_STREAM=0/1 forces the choice (A/B runs).
+static bool stream_ok(const InGeo &g, int H, long long num_src) {
+    static const char *force = getenv("GATMI_STREAM");
+    if (!(g.G == 64 && g.Fs / 4 <= 64 && H <= kStreamMaxHeads)) return false;
+    if (force && force[0] == '0') return false;
+    if (force && force[0] == '1') return true;
+    return num_src * g.Fs * 4 > (256ll << 20);
 }
 
 // Persistent grid: as many blocks as fit on the device at once; chunks come from the queue.
@@ -834,10 +863,23 @@ static void stream_launch(InKind k, const InArgs &A, hipStream_t st) {
     }
 }
 
-static int stream_launch_rows(InKind k, const InGeo &g, InArgs &A, hipStream_t st) {
-    A.n_chunks = (A.n_items + kChunkItems - 1) / kChunkItems;
-    if (A.n_chunks == 0) return GATMI_OK;
+static size_t stream_ws_ints(const gatmi_graph *g) {
+    return 64 + ((size_t)g->num_edges >> kChunkEdgesLog) + 2;   // queue | chunk_item
+}
+
+static int stream_launch_rows(InKind k, const InGeo &g, InArgs &A, int *ws, hipStream_t st) {
+    if (A.n_items == 0) return GATMI_OK;
+    A.n_chunks = (A.E >> kChunkEdgesLog) + 1;
+    A.queue = ws;
+    int *table = ws + 64;
+    A.chunk_item = table;
     GATMI_HIP(hipMemsetAsync(A.queue, 0, sizeof(int), st));
+    {
+        const int blocks = (A.n_items + 256) / 256;
+        hipLaunchKernelGGL(inagg_chunk_table_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256),
+                           0, st, A.item_beg, A.n_items, A.n_chunks, table);
+        GATMI_HIP(hipGetLastError());
+    }
     if (g.LH == 16 && g.T == 2) stream_launch<16, 2>(k, A, st);
     else if (g.LH == 8 && g.T == 1) stream_launch<8, 1>(k, A, st);
     else if (g.T == 1) stream_launch<0, 1>(k, A, st);
@@ -986,7 +1028,7 @@ extern "C" size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const ga
     cv.take<float>(slots * s->heads);
     cv.take<float>(slots * s->heads);
     cv.take<float>(slots * geo.HF);
-    cv.take<int>(64);   // chunk queue of the streaming kernel
+    cv.take<int>(stream_ws_ints(g));   // chunk queue + table of the streaming kernel
     return cv.off + 256;
 }
 
@@ -1010,13 +1052,13 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
     A.part_m = cv.take<float>(slots * H);
     A.part_s = cv.take<float>(slots * H);
     A.part_acc = cv.take<float>(slots * geo.HF);
-    A.queue = cv.take<int>(64);
+    int *stream_ws = cv.take<int>(stream_ws_ints(g));
     A.z = z;
     A.lse = lse;
     {
         ProfScope ps("inagg_fwd", st);
-        if (stream_ok(geo, H)) {
-            if (int e = stream_launch_rows(IN_FWD, geo, A, st)) return e;
+        if (stream_ok(geo, H, g->num_src)) {
+            if (int e = stream_launch_rows(IN_FWD, geo, A, stream_ws, st)) return e;
         } else if (int e = in_launch_rows(IN_FWD, geo, A, in_grid(geo, A.n_items), st)) {
             return e;
         }
