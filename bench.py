@@ -29,14 +29,16 @@ def kernel_bytes(n, e, h, d, f):
     edge, the grad_out row (4D), the destination's 16H-byte record, col_t and pos_t, and
     writes d_u (4H); per node it reads h, writes d_h and d_a_src."""
     fp = (f + 3) // 4 * 4
+    fs = fp + (h + 3) // 4 * 4        # packed source row: x | a_src
     return {
         "attn_fwd": e * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
         "attn_bwd_edge": e * (4 * d + 16 * h + 8 + 4 * h) + n * (8 * d + 4 * h),
-        # input-side aggregation (gat_amd/csrc/inagg.hip): an edge moves an x row (4 Fp) and its
-        # col index; a node reads rowptr and its own x row, writes Z [H, Fp] and lse (forward),
-        # reads q, Z [H, Fp] and lse (backward; nothing is written per edge or per node)
-        "inagg_fwd": e * (4 * fp + 4) + n * (4 + 4 * fp + 4 * h * fp + 4 * h),
-        "inagg_bwd_edge": e * (4 * fp + 4) + n * (4 + 4 * fp + 8 * h * fp + 4 * h),
+        # input-side aggregation (gat_amd/csrc/inagg.hip): an edge moves a packed source row
+        # x | a_src (4 Fs bytes) and its col index; a node reads rowptr and a_dst, writes Z [H, Fp]
+        # and lse (forward); reads its own packed row, q and Z [H, Fp], a_dst and lse (backward;
+        # nothing is written per edge or per node)
+        "inagg_fwd": e * (4 * fs + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h),
+        "inagg_bwd_edge": e * (4 * fs + 4) + n * (4 + 4 * fs + 8 * h * fp + 8 * h),
     }
 
 

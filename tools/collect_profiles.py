@@ -52,10 +52,15 @@ def main():
     open(os.path.join(dst, f"pmc_{prefix}.txt"), "w").write("\n".join(lines) + "\n")
     tags = {"inagg_fwd": ["inagg_fwd_stream_kernel", "inagg_fwd_kernel"], "inagg_bwd_edge": ["inagg_bwd_kernel"],
             "attn_fwd": ["attn_fwd_kernel"], "attn_bwd_edge": ["attn_bwd_edge_kernel"]}
+    old = {}
+    try:    # kernels this run did not launch keep their earlier measurement
+        old = json.load(open(os.path.join(dst, "pmc_traffic.json"))).get("kernels", {})
+    except (OSError, ValueError):
+        pass
     out = {"workload": "products",
            "note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
                    f"passes (profiles: pmc_{prefix}.txt); FETCH_SIZE doubled per MI355X_MICROARCH.md",
-           "kernels": {}}
+           "kernels": dict(old)}
     for tag_, names in tags.items():
         for n in names:
             if n in traffic:
