@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.425)  # run.py:21, attention dropout on
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--input-aggregation", default="auto", choices=["auto", "on", "off"],
+                    help="N=1: aggregate x rows per head before projecting (gat_amd/csrc/inagg.hip); "
+                         "auto = what GATConv picks (on here: x carries no gradient, F < H*C)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "h", "x", "xs", "as"],
                     help="N>1: what the destination partition all-gathers (gat_amd/dist.py)")
     args = ap.parse_args()
@@ -131,7 +134,9 @@ def main():
     g = torch.Generator(device=dev).manual_seed(args.seed)
     x = torch.randn(n, f, generator=g, device=dev)
     torch.manual_seed(args.seed)
-    conv = GATConv(f, c, heads=h, dropout=args.dropout).to(dev).train()
+    conv = GATConv(f, c, heads=h, dropout=args.dropout,
+                   input_aggregation={"auto": None, "on": True, "off": False}[args.input_aggregation]
+                   ).to(dev).train()
 
     torch.cuda.synchronize()
     t0 = time.time()
@@ -183,7 +188,9 @@ def main():
                                   f"{ei.size(1)} edges ({ep} after self-loop normalisation), "
                                   f"one GAT layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
                       "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
-                      "parallelism": "single GPU", "graph_layout_build_s": round(t_layout, 4)},
+                      "parallelism": "single GPU",
+                      "path": "input-side aggregation" if "inagg_fwd" in avg else "projected rows",
+                      "graph_layout_build_s": round(t_layout, 4)},
            "roofline": roofline, "kernels": kernels}
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
