@@ -50,7 +50,7 @@ class Attn(C.Structure):
 
 class InAgg(C.Structure):
     _fields_ = [("shape", Shape), ("negative_slope", C.c_float), ("dropout_p", C.c_float),
-                ("mask_mode", C.c_int32), ("_pad", C.c_int32), ("seed", C.c_uint64),
+                ("mask_mode", C.c_int32), ("stream", C.c_int32), ("seed", C.c_uint64),
                 ("mask", C.c_void_p), ("xs", C.c_void_p), ("a_dst", C.c_void_p),
                 ("weight", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p),
                 ("bias", C.c_void_p)]

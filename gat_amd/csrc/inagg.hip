@@ -833,11 +833,11 @@ static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, h
 // They pay when the packed table is far larger than the 256 MiB Infinity Cache (rows come
 // from HBM and bytes in flight decide); a cache-resident table is served faster by the
 // register pipeline (lower per-edge overhead).  GATMI_STREAM=0/1 forces the choice (A/B runs).
-static bool stream_ok(const InGeo &g, int H, long long num_src) {
+static bool stream_ok(const InGeo &g, int H, long long num_src, int mode) {
     static const char *force = getenv("GATMI_STREAM");
     if (!(g.G == 64 && g.Fs / 4 <= 64 && H <= kStreamMaxHeads)) return false;
-    if (force && force[0] == '0') return false;
-    if (force && force[0] == '1') return true;
+    if (mode == 2 || (mode == 0 && force && force[0] == '0')) return false;
+    if (mode == 1 || (mode == 0 && force && force[0] == '1')) return true;
     return num_src * g.Fs * 4 > (256ll << 20);
 }
 
@@ -906,6 +906,7 @@ static int check_inagg(const gatmi_graph *g, const gatmi_inagg *a, InGeo *geo) {
     GATMI_REQUIRE(a->mask_mode != GATMI_MASK_BYTES || a->mask, "mask_mode BYTES needs a mask");
     GATMI_REQUIRE(a->dropout_p >= 0.f && a->dropout_p <= 1.f, "dropout_p %f outside [0,1]",
                   a->dropout_p);
+    GATMI_REQUIRE(a->stream >= 0 && a->stream <= 2, "bad stream mode %d", a->stream);
     GATMI_REQUIRE(a->xs && a->a_dst && a->weight && a->att_src && a->att_dst,
                   "null xs/a_dst/weight/att_src/att_dst");
     return GATMI_OK;
@@ -1057,7 +1058,7 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
     A.lse = lse;
     {
         ProfScope ps("inagg_fwd", st);
-        if (stream_ok(geo, H, g->num_src)) {
+        if (stream_ok(geo, H, g->num_src, a->stream)) {
             if (int e = stream_launch_rows(IN_FWD, geo, A, stream_ws, st)) return e;
         } else if (int e = in_launch_rows(IN_FWD, geo, A, in_grid(geo, A.n_items), st)) {
             return e;

@@ -93,7 +93,7 @@ class GATConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
                  negative_slope: float = 0.2, dropout: float = 0.0, add_self_loops: bool = True,
                  bias: bool = True, seg_len: int = DEFAULT_SEG_LEN,
-                 input_aggregation: Optional[bool] = None):
+                 input_aggregation: Optional[bool] = None, stream: Optional[bool] = None):
         super().__init__()
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
@@ -102,6 +102,9 @@ class GATConv(nn.Module):
         # None: aggregate x before projecting whenever that is possible and cheaper (x needs
         # no gradient, F < H*Cp); True/False force the choice (True raises when impossible)
         self.input_aggregation = input_aggregation
+        # input-side aggregation forward: None = by table size, True/False force the LDS-DMA
+        # streaming kernel / the register pipeline (tests, A/B runs)
+        self.stream = stream
         self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
         self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
@@ -138,6 +141,7 @@ class GATConv(nn.Module):
         fused_bias = self.bias if self.concat else None
         cfg = ops.AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
                              mask_mode, seed, mask)
+        cfg.stream = 0 if self.stream is None else (1 if self.stream else 2)
         x_grad = x.requires_grad and torch.is_grad_enabled()
         use_inagg = self.input_aggregation
         if use_inagg is None:

@@ -37,6 +37,7 @@ class AttnConfig:
         self.heads, self.channels = heads, channels
         self.negative_slope, self.dropout = float(negative_slope), float(dropout)
         self.mask_mode, self.seed, self.mask = mask_mode, seed, mask
+        self.stream = 0     # input-side aggregation forward: 0 auto, 1 streaming, 2 registers
 
     def c_args(self, num_dst, in_features, hp, a_dst, att_src, att_dst, bias):
         a = _lib.Attn()
@@ -163,6 +164,7 @@ def _inagg_args(cfg: AttnConfig, num_dst, in_features, xs, a_dst, weight, att_sr
     a.shape = _lib.Shape(num_dst, in_features, cfg.heads, cfg.channels)
     a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
     a.mask_mode, a.seed, a.mask = cfg.mask_mode, cfg.seed, _ptr(cfg.mask)
+    a.stream = int(getattr(cfg, "stream", 0))
     a.xs, a.a_dst, a.weight = xs.data_ptr(), a_dst.data_ptr(), weight.data_ptr()
     a.att_src, a.att_dst, a.bias = _ptr(att_src), _ptr(att_dst), _ptr(bias)
     return a

@@ -216,7 +216,9 @@ typedef struct gatmi_inagg {
     float negative_slope;
     float dropout_p;
     int32_t mask_mode;     /* GATMI_MASK_*                                              */
-    int32_t _pad;
+    int32_t stream;        /* forward kernel: 0 = pick by table size (LDS-DMA streaming when
+                              the packed table exceeds the 256 MiB Infinity Cache), 1 = streaming,
+                              2 = register pipeline; same results up to fp32 re-association */
     uint64_t seed;
     const uint8_t *mask;   /* GATMI_MASK_BYTES: [E', H] keep flags, dst-CSR order       */
     const float *xs;       /* [num_src, Fs] packed source rows (all nodes of the graph) */

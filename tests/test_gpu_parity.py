@@ -130,13 +130,13 @@ def test_projection_fwd_bwd(cuda, n, f, h, c):
 
 
 # ------------------------------------------------------------------ whole layer
-def run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs=None, concat=True, inagg=False):
+def run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs=None, concat=True, inagg=False, stream=None):
     """inagg=True: x carries no gradient and the layer must take the input-side aggregation
     path (gatmi_inagg_*); the returned grads then have no "x" entry."""
     from gat_amd import GATConv
     x, w, a_s, a_d, b, go = inputs if inputs is not None else cases.layer_inputs(n, f, h, c)
     conv = GATConv(f, c, heads=h, dropout=p, seg_len=seg,
-                   input_aggregation=True if inagg else False).to(cuda)
+                   input_aggregation=True if inagg else False, stream=stream).to(cuda)
     with torch.no_grad():
         conv.lin.weight.copy_(w)
         conv.att_src.copy_(a_s)
@@ -195,10 +195,12 @@ INAGG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("stream", [True, False], ids=["stream", "registers"])
 @pytest.mark.parametrize("gname,sname,p,seg", INAGG_CASES)
-def test_input_aggregation_matches_oracle(cuda, gname, sname, p, seg):
+def test_input_aggregation_matches_oracle(cuda, gname, sname, p, seg, stream):
     """The input-side aggregation path (x without gradient, F < H*Cp): output and parameter
-    gradients against the same oracle as the projected-row path."""
+    gradients against the same oracle as the projected-row path, with the forward on the
+    LDS-DMA streaming kernel (where it covers the shape) and on the register pipeline."""
     ei, n = cases.GRAPHS[gname]()
     f, h, c = cases.SHAPES[sname]
     inputs = cases.layer_inputs(n, f, h, c)
@@ -207,11 +209,55 @@ def test_input_aggregation_matches_oracle(cuda, gname, sname, p, seg):
     mask = cases.keep_mask(ne, h, p) if p > 0 else None
     ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
                                               mask=mask, training=p > 0)
-    out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=True)
+    out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=True, stream=stream)
     close(out, ref_out, "out")
     summand = float(go.abs().max() * (x @ w.t()).abs().max())
     for k in g:
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
+def test_streaming_forward_medium_graph(cuda):
+    """300k-node power-law graph (hubs cut into 512-edge segments, many chunks, col windows
+    crossed many times): the streaming forward, forced on, against the oracle; then its
+    backward; then streaming == register pipeline to re-association."""
+    from gat_amd import synth
+    n, e = 60000, 900000
+    ei = synth.powerlaw_graph(n, e, 6000, seed=3)
+    f, h, c = cases.SHAPES["products_l1"]
+    inputs = cases.layer_inputs(n, f, h, c, seed=7)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True, stream=True)
+    close(out, ref_out, "out")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+    out2, _ = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True, stream=False)
+    close(out, out2, "stream vs registers")
+
+
+def test_input_aggregation_properties_at_scale(cuda):
+    """products-sized table (beyond the Infinity Cache: the streaming kernel is what auto picks):
+    identical rows in -> identical rows + bias out (the softmax weights of every destination sum
+    to one), and the parameter gradients are linear in grad_out."""
+    from gat_amd import GATConv, synth
+    n, e = 700000, 9000000
+    f, h, c = cases.SHAPES["products_l1"]
+    ei = synth.powerlaw_graph(n, e, 9000, seed=1, device=cuda)
+    conv = GATConv(f, c, heads=h, stream=True).to(cuda).eval()
+    x = torch.randn(1, f, device=cuda).expand(n, f).contiguous()
+    out = conv(x, ei)
+    expect = (x[:1] @ conv.lin.weight.t()) + conv.bias
+    close(out, expect.expand(n, -1), "constant rows")
+    xr = torch.randn(n, f, device=cuda)
+    g1 = torch.randn(n, h * c, device=cuda); g2 = torch.randn(n, h * c, device=cuda)
+    def wgrad(go):
+        conv.zero_grad()
+        conv(xr, ei).backward(go)
+        return conv.lin.weight.grad.clone(), conv.att_src.grad.clone()
+    a, b, cc = wgrad(g1), wgrad(g2), wgrad(g1 + 2 * g2)
+    for u, v, t in zip(a, b, cc):
+        assert float((u + 2 * v - t).abs().max() / t.abs().max()) < 2e-5
 
 
 def test_input_aggregation_is_chosen_and_agrees_with_projected_rows(cuda):
@@ -270,8 +316,9 @@ def test_input_aggregation_random_sweep(cuda):
         mask = cases.keep_mask(ne, h, p, seed=trial) if p > 0 else None
         ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
                                                   mask=mask, training=p > 0)
-        out, gr = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=True)
-        tag = f"trial {trial}: n={n} e={e} h={h} c={c} f={f} p={p} seg={seg}"
+        stream = bool(trial & 1)
+        out, gr = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=True, stream=stream)
+        tag = f"trial {trial}: n={n} e={e} h={h} c={c} f={f} p={p} seg={seg} stream={stream}"
         close(out, ref_out, tag + " out")
         summand = float(go.abs().max() * (x @ w.t()).abs().max())
         for k in gr:
@@ -488,6 +535,7 @@ def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world):
     ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
     be = HipBackend(seg_len=64)
     cfg = ops.AttnConfig(h, c)
+    cfg.stream = 1 + world % 2          # streaming forward for odd worlds, registers for even
     xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
     asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
     parts = [Partition(n, world, r) for r in range(world)]
