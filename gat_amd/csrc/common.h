@@ -98,10 +98,14 @@ struct GemmDesc {
     const float *B; int ldb; long long sB;
     float *C; int ldc; long long sC, sSplit;
     int M, Nn, K, n_store, nbatch, nsplit;
+    int a_kpad;   // K-resident kernel only: A rows are zero padded to this many columns (0: K)
     const float *bias; long long sBias;
     AFix fix;
     float *asum;   // see GemmBatch
 };
 int launch_gemm(const GemmDesc &d, hipStream_t st);
+// tall row-major A (16-byte aligned rows, K <= 128), small B kept in LDS: see project.hip
+bool kres_covers(const GemmDesc &d);
+int launch_kres(const GemmDesc &d, hipStream_t st);
 
 }  // namespace gatmi

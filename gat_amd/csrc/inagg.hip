@@ -1082,7 +1082,8 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
         d.M = N; d.Nn = C; d.K = F; d.n_store = C; d.nbatch = H; d.nsplit = 1;
         d.bias = a->bias; d.sBias = C;
         d.fix = AFix{nullptr, nullptr, 1, 1};
-        if (int e = launch_gemm(d, st)) return e;
+        d.a_kpad = geo.Fp;   // the padded columns of Z are zero
+        if (int e = kres_covers(d) ? launch_kres(d, st) : launch_gemm(d, st)) return e;
     }
     return GATMI_OK;
 }
@@ -1143,7 +1144,7 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         d.M = N; d.Nn = F; d.K = C; d.n_store = geo.Fp; d.nbatch = H; d.nsplit = 1;
         d.bias = nullptr; d.sBias = 0;
         d.fix = AFix{nullptr, nullptr, 1, 1};
-        if (int e = launch_gemm(d, st)) return e;
+        if (int e = kres_covers(d) ? launch_kres(d, st) : launch_gemm(d, st)) return e;
     }
     A.q = w.q;
     A.zin = z;

@@ -10,6 +10,7 @@
 // Wp is the weight with each head's rows padded from C to Cp (zero rows), so the output
 // lands directly in the head-padded layout the attention kernels gather from.
 #include "common.h"
+#include <stdlib.h>
 
 namespace gatmi {
 
@@ -255,6 +256,228 @@ __global__ __launch_bounds__(256) void row_dots_flat_kernel(const float *hp, con
             if (q < nq && sub == 0) a_dst[grp] = p;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// K-resident GEMM for a tall row-major A and a small B (K <= 128, N <= 128 per batch): the
+// out = Z W^T and q = g W products of the input-side aggregation path, one batch per head.
+// The tiled kernel above spends half its wave cycles parked at waitcnt/barriers on these
+// shapes (K is 4-7 of its k-tiles: every block is mostly prologue and epilogue).  Here
+//   * B (zero padded to [Kp][NT*32]) sits in LDS for the lifetime of a persistent block;
+//   * every wave owns tiles of 32 rows and stages them itself, global -> LDS by LDS-DMA
+//     (no VGPRs), two tile buffers per wave, the next tile in flight while this one is
+//     multiplied -- waves never meet at a barrier after the B fill;
+//   * A operands are read with ds_read_b128: lane (l, half) takes chunk 2j + half of row l, and
+//     the contraction order is permuted to match (k = 8j + 4 half + i in step (j, i)).  A row
+//     stride of nf4 * 16 bytes is conflict-free for odd nf4; nf4 == 16 uses an XOR swizzle
+//     applied on the SOURCE address of the DMA (its LDS image is lane-linear).
+// ---------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void kres_dma16(const void *g, void *lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_uniform, 16,
+                                     0, 0);
+}
+template <int N> __device__ __forceinline__ void kres_wait_imm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void kres_wait_vm(int n) {   // n wave-uniform, <= 32 here
+    switch (n) {
+        case 0: kres_wait_imm<0>(); break;
+        case 1: kres_wait_imm<1>(); break;
+        case 2: kres_wait_imm<2>(); break;
+        case 3: kres_wait_imm<3>(); break;
+        case 4: kres_wait_imm<4>(); break;
+        case 5: kres_wait_imm<5>(); break;
+        case 6: kres_wait_imm<6>(); break;
+        case 7: kres_wait_imm<7>(); break;
+        case 8: kres_wait_imm<8>(); break;
+        case 9: kres_wait_imm<9>(); break;
+        case 10: kres_wait_imm<10>(); break;
+        case 11: kres_wait_imm<11>(); break;
+        case 12: kres_wait_imm<12>(); break;
+        case 13: kres_wait_imm<13>(); break;
+        case 14: kres_wait_imm<14>(); break;
+        case 15: kres_wait_imm<15>(); break;
+        case 16: kres_wait_imm<16>(); break;
+        case 32: kres_wait_imm<32>(); break;
+        default: kres_wait_imm<0>(); break;
+    }
+}
+
+template <int NT, bool SWZ>
+__global__ __launch_bounds__(256, 1) void gemm_kres_kernel(const float *__restrict__ A, int lda,
+                                                           const float *__restrict__ B, int ldb,
+                                                           int b_kmajor, float *__restrict__ C,
+                                                           int ldc, int M, int Nn, int K, int nf4,
+                                                           const GemmBatch gb) {
+    constexpr int LDB = NT * 32;
+    // B in a static array, the A tile buffers in the dynamic one: hipcc makes every LDS read that
+    // may alias an LDS-DMA in flight wait for it (vmcnt(0) inside the MFMA loop: no prefetch left);
+    // two distinct objects let it see that the B reads do not.  The A reads go through inline
+    // asm for the same reason -- their ordering against the DMA is the counted wait below.
+    __shared__ float Bl[128 * LDB];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Kp = (nf4 * 4 + 7) & ~7;
+    const int batch = blockIdx.y;
+    A += (size_t)batch * gb.sA;
+    B += (size_t)batch * gb.sB;
+    C += (size_t)batch * gb.sC;
+    const float *bias = gb.bias ? gb.bias + (size_t)batch * gb.sBias : nullptr;
+    for (int idx = threadIdx.x; idx < Kp * LDB; idx += 256) {
+        const int k = idx / LDB, n = idx % LDB;
+        float v = 0.f;
+        if (k < K && n < Nn) v = b_kmajor ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
+        Bl[idx] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const unsigned rowb = (unsigned)nf4 * 16u, tileb = 32u * rowb;
+    char *abuf = smem + (size_t)wave * 2 * tileb;
+    const int rpi = 64 / nf4;                   // rows per DMA instruction
+    const int ninstr = (32 + rpi - 1) / rpi;
+    const int er = lane / nf4, ep = lane - er * nf4;
+    const bool dma_on = er < rpi;
+    const long long ntiles = ((long long)M + 31) / 32;
+    const long long tstride = (long long)gridDim.x * 4;
+    auto issue = [&](long long tile, int buf) {
+        char *dst = abuf + buf * tileb;
+        for (int i = 0; i < ninstr; ++i) {
+            const int rl = i * rpi + er;                        // row inside the tile
+            long long row = tile * 32 + (rl < 32 ? rl : 31);
+            row = row < M ? row : (long long)M - 1;
+            const int piece = SWZ ? (ep ^ (rl & 15)) : ep;
+            const float *g = A + row * lda + piece * 4;
+            if (dma_on && rl < 32) kres_dma16(g, dst + (unsigned)(i * rpi) * rowb);
+        }
+    };
+    const float *bl = Bl + (4 * half) * LDB + l;
+    const int KC = (nf4 + 1) >> 1;
+    // bias of this lane's columns, fetched (and waited for) before any DMA is in flight: the use
+    // of an ordinary load's result later on would make hipcc drain the DMA queue with vmcnt(0)
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cn = nt * 32 + l;
+        bv[nt] = (bias && cn < Nn) ? bias[cn] : 0.f;
+        asm volatile("" : "+v"(bv[nt]));
+    }
+    // Order of a wave's vector-memory operations: ... stores(t-1), DMA(t+1) | wait(t), MFMA(t),
+    // stores(t), DMA(t+2) ...  vmcnt counts loads and stores alike; loads retire in order, so
+    // "at most ninstr outstanding" = tile t has landed.  The stores younger than DMA(t) were
+    // issued a whole tile ago, so the wait does not stall on them (it does when a tile's DMA is
+    // issued right after the previous tile's stores: 6.4 instead of 3.1 ms for q = g W).
+    long long t = (long long)blockIdx.x * 4 + wave;
+    int buf = 0;
+    if (t < ntiles) issue(t, 0);
+    if (t + tstride < ntiles) issue(t + tstride, 1);
+    for (; t < ntiles; t += tstride, buf ^= 1) {
+        kres_wait_vm(t + tstride < ntiles ? ninstr : 0);
+        const char *at = abuf + buf * tileb + (unsigned)l * rowb;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        int boff = 0;                            // keep the B reads inside the tile loop: an opaque
+        asm volatile("" : "+v"(boff));           // OFFSET (laundering the pointer itself makes it
+        const float *blt = bl + boff;            // generic: flat loads that wait on vmcnt too)
+
+        for (int j = 0; j < KC; ++j) {
+            const int c = 2 * j + half;
+            f32x4 a4;
+            {
+                const int cc = c < nf4 ? c : 0;   // the pad chunk multiplies zero rows of B
+                const unsigned addr = (unsigned)(uintptr_t)(
+                    (const __attribute__((address_space(3))) char *)(at + (SWZ ? (cc ^ (l & 15)) : cc) * 16));
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a4) : "v"(addr) : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        a4[i], blt[(8 * j + i) * LDB + nt * 32], acc[nt], 0, 0, 0);
+        }
+        const long long row0 = t * 32;
+        const bool full = row0 + 32 <= M;        // one branch per tile, not one per store
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cn = nt * 32 + l;
+            if (cn < gb.n_store) {
+                float *cp = C + (size_t)(row0 + 4 * half) * ldc + cn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (full || row0 + 4 * half + dr < M) cp[(size_t)dr * ldc] = acc[nt][r] + bv[nt];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this buffer's reads have landed
+        if (t + 2 * tstride < ntiles) issue(t + 2 * tstride, buf);
+    }
+}
+
+static size_t kres_dyn_lds(int nf4) { return (size_t)4 * 2 * 32 * nf4 * 16; }
+static size_t kres_lds_bytes(int nf4, int NT) {
+    return (size_t)128 * NT * 32 * 4 + kres_dyn_lds(nf4);
+}
+
+// true when the K-resident kernel covers the product (else use launch_gemm)
+bool kres_covers(const GemmDesc &d) {
+    static const char *env = getenv("GATMI_KRES");   // A/B switch: 0 = tiled kernel
+    if (env && env[0] == '0') return false;
+    const int ka = d.a_kpad > d.K ? d.a_kpad : d.K;  // A's zero-padded row length, if longer
+    const int nf4 = ka / 4;
+    const int nstore = d.n_store > d.Nn ? d.n_store : d.Nn;
+    if (d.a_kmajor || d.nsplit > 1 || d.K < 1 || ka > 128 || (ka & 3) || nstore > 128) return false;
+    if ((d.lda & 3) || (d.sA & 3) || (reinterpret_cast<uintptr_t>(d.A) & 15) || d.fix.da_dst) return false;
+    if (!((nf4 & 1) || nf4 == 16)) return false;     // conflict-free LDS image: odd stride or swizzle
+    if (d.nbatch > 65535 || d.M < 4096) return false;
+    return kres_lds_bytes(nf4, nstore <= 32 ? 1 : (nstore <= 64 ? 2 : 4)) <= 160 * 1024;
+}
+
+template <int NT, bool SWZ>
+static void kres_launch(const GemmDesc &d, int nf4, hipStream_t st) {
+    const size_t lds = kres_dyn_lds(nf4), lds_all = kres_lds_bytes(nf4, NT);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            cus = 256;
+    }
+    static size_t dyn_cap = 0;   // dynamic LDS beyond 64 KiB has to be granted per kernel
+    if (lds > dyn_cap) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kres_kernel<NT, SWZ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            dyn_cap = lds;
+    }
+    const int per_cu = (int)((160 * 1024) / lds_all) < 1 ? 1 : (int)((160 * 1024) / lds_all);
+    long long bx = ((long long)cus * per_cu + d.nbatch - 1) / d.nbatch;   // one resident set
+    const long long need = (((long long)d.M + 31) / 32 + 3) / 4;
+    if (bx > need) bx = need;
+    if (bx < 1) bx = 1;
+    GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, 1, d.n_store, nullptr};
+    hipLaunchKernelGGL((gemm_kres_kernel<NT, SWZ>), dim3((unsigned)bx, d.nbatch), dim3(256), lds, st,
+                       d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, gb);
+}
+
+int launch_kres(const GemmDesc &d0, hipStream_t st) {
+    GemmDesc d = d0;
+    if (d.n_store < d.Nn) d.n_store = d.Nn;
+    if (d.nbatch < 1) d.nbatch = 1;
+    if (d.M == 0 || d.Nn == 0) return GATMI_OK;
+    GATMI_REQUIRE(kres_covers(d), "K-resident GEMM does not cover this product");
+    const int nf4 = (d.a_kpad > d.K ? d.a_kpad : d.K) / 4;
+    const bool swz = nf4 == 16;
+    if (d.n_store <= 32) swz ? kres_launch<1, true>(d, nf4, st) : kres_launch<1, false>(d, nf4, st);
+    else if (d.n_store <= 64) swz ? kres_launch<2, true>(d, nf4, st) : kres_launch<2, false>(d, nf4, st);
+    else swz ? kres_launch<4, true>(d, nf4, st) : kres_launch<4, false>(d, nf4, st);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
 }
 
 template <bool AK, bool BK_, int BM, int BN>
