@@ -1,0 +1,23 @@
+"""Per-GEMM MFMA utilisation from the two PMC passes of tools/pmc_mfma.sh -> profiles/<round>/pmc_mfma.txt"""
+import csv, glob, re, sys
+from collections import defaultdict
+dst = sys.argv[1] if len(sys.argv) > 1 else "profiles/r1/pmc_mfma.txt"
+out = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (one pass per variant),",
+       "# bench.py --steps 2 --warmup 1, products-shaped.  GRBM_GUI_ACTIVE is summed over the 8 XCDs;",
+       "# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)  (v_mfma_f32_32x32x2_f32 = 64 busy cycles)"]
+for v, label in (("auto", "input-side aggregation path (gemm_kres<2,false>: out = Z W^T | gemm_kres<4,true>: q = g W | gemm_f32<true,true,64,128>: dW = g^T Z)"),
+                 ("off", "projected-row path (gemm_f32<false,false,..>: h = x W^T | gemm_f32<true,true,..>: dW = d_h^T x)")):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(f"gpurun_out/pmc_mfma_{v}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            m = re.search(r"gatmi::(gemm_\w+<[^>]*>)", row["Kernel_Name"])
+            if m:
+                acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out.append(f"== {label}")
+    for k in sorted(acc):
+        c = {n: sum(x) / len(x) for n, x in acc[k].items()}
+        util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        out.append(f"{k:44s} n={len(acc[k]['GRBM_GUI_ACTIVE'])} GRBM_GUI_ACTIVE {c['GRBM_GUI_ACTIVE']:.0f}  MFMA_BUSY {c['SQ_VALU_MFMA_BUSY_CYCLES']:.0f}  "
+                   f"MOPS_F32 {c['SQ_INSTS_VALU_MFMA_MOPS_F32']:.0f}  SQ_BUSY {c['SQ_BUSY_CYCLES']:.0f}  -> MFMA utilisation {100 * util:.1f} %")
+open(dst, "w").write("\n".join(out) + "\n")
+print("\n".join(out))
