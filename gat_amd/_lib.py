@@ -56,6 +56,13 @@ class InAgg(C.Structure):
                 ("bias", C.c_void_p)]
 
 
+class Glue(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int32), ("training", C.c_int32),
+                ("eps", C.c_float), ("momentum", C.c_float), ("dropout_p", C.c_float),
+                ("_pad", C.c_int32), ("seed", C.c_uint64), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/gat_mi355.h declares
 SYMBOLS = {
     "gatmi_last_error": (C.c_char_p, []),
@@ -83,6 +90,14 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_add_dst_term": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "gatmi_glue_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "gatmi_glue_fwd": (C.c_int, [C.POINTER(Glue), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_glue_bwd": (C.c_int, [C.POINTER(Glue), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
+    "gatmi_glue_mask": (C.c_int, [C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
+                                  C.c_void_p]),
     "gatmi_inagg_supported": (C.c_int, [C.POINTER(Shape)]),
     "gatmi_inagg_z_floats": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_inagg_xs_floats": (C.c_size_t, [C.POINTER(Shape)]),

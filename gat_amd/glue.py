@@ -1,0 +1,100 @@
+"""ELU -> BatchNorm1d -> Dropout between two GAT layers, fused (gat_amd/csrc/glue.hip).
+
+The reference writes it as three calls, /root/reference/gat/model.py:40-42 and :43-45:
+    x = F.elu(conv(x, edge_index)); x = self.bn(x); x = self.dropout(x)
+`elu_bn_dropout(x, bn, p)` computes the same thing from the same `nn.BatchNorm1d` module (its
+weight, bias and running statistics stay where checkpoints expect them) in two passes over the
+activations forward and two backward.  GPU only, fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+def _desc(rows, cols, training, eps, momentum, p, seed, gamma, beta, rmean, rvar):
+    g = _lib.Glue()
+    g.rows, g.cols, g.training = rows, cols, int(training)
+    g.eps, g.momentum, g.dropout_p, g.seed = float(eps), float(momentum), float(p), int(seed)
+    g.gamma, g.beta = gamma.data_ptr(), beta.data_ptr()
+    g.running_mean = None if rmean is None else rmean.data_ptr()
+    g.running_var = None if rvar is None else rvar.data_ptr()
+    return g
+
+
+def _ws(cols, dev):
+    return torch.empty(int(_lib.lib().gatmi_glue_workspace_bytes(cols)), dtype=torch.uint8, device=dev)
+
+
+class _GlueFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps, momentum, p, seed):
+        lib, dev = _lib.lib(), x.device
+        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        n, d = x.shape
+        with torch.cuda.device(dev):
+            y = torch.empty_like(x)
+            mean = torch.empty(d, dtype=torch.float32, device=dev)
+            rstd = torch.empty(d, dtype=torch.float32, device=dev)
+            ws = _ws(d, dev)
+            g = _desc(n, d, training, eps, momentum, p, seed, gamma, beta, rmean, rvar)
+            _lib.check(lib.gatmi_glue_fwd(C.byref(g), x.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "gatmi_glue_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (training, eps, momentum, p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, eps, momentum, p, seed = ctx.cfg
+        lib, dev = _lib.lib(), x.device
+        n, d = x.shape
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(x)
+            dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+            ws = _ws(d, dev)
+            # running statistics are not touched by the backward: pass the saved ones as such
+            g = _desc(n, d, training, eps, momentum, p, seed, gamma, beta, mean, rstd)
+            _lib.check(lib.gatmi_glue_bwd(C.byref(g), x.data_ptr(), grad_y.contiguous().data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), gx.data_ptr(),
+                                          dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "gatmi_glue_bwd")
+        return gx, dg, db, None, None, None, None, None, None, None
+
+
+def elu_bn_dropout(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int = None) -> Tensor:
+    """dropout(bn(elu(x))) with `bn`'s parameters and running statistics (updated in training,
+    like the module would).  `seed` fixes the dropout mask (tests); default: drawn from torch's
+    generator."""
+    if not x.is_cuda:
+        raise RuntimeError("gat_amd.glue runs on the GPU only (no CPU fallback)")
+    if x.dim() != 2 or x.size(1) != bn.num_features:
+        raise ValueError(f"x must be [N, {bn.num_features}], got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise TypeError(f"x must be float32, got {x.dtype}")
+    if not bn.affine or not bn.track_running_stats or bn.momentum is None:
+        raise ValueError("elu_bn_dropout covers nn.BatchNorm1d's defaults (affine, running statistics, "
+                         "momentum), as the reference constructs it at model.py:27,29")
+    drop = training and p > 0.0
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop else 0
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _GlueFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps,
+                         bn.momentum, p if training else 0.0, seed)
+
+
+def dropout_mask(rows: int, cols: int, p: float, seed: int, device) -> Tensor:
+    """The keep-mask elu_bn_dropout uses for (p, seed), as a bool tensor [rows, cols]."""
+    mask = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().gatmi_glue_mask(rows, cols, float(p), int(seed), mask.data_ptr(),
+                                              torch.cuda.current_stream(device).cuda_stream),
+                   "gatmi_glue_mask")
+    return mask.bool()

@@ -145,8 +145,9 @@ class GATConv(nn.Module):
         x_grad = x.requires_grad and torch.is_grad_enabled()
         use_inagg = self.input_aggregation
         if use_inagg is None:
-            use_inagg = not x_grad and ops.inagg_supported(self.in_channels, self.heads,
-                                                           self.out_channels)
+            use_inagg = not x_grad and ops.inagg_supported(
+                self.in_channels, self.heads, self.out_channels,
+                layout.num_edges / max(layout.num_dst, 1))
         elif use_inagg and x_grad:
             raise RuntimeError("input_aggregation=True cannot produce a gradient for x")
         fn = _GATConvInAggFn if use_inagg else _GATConvFn

@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .data import Data, Metrics
+from .glue import elu_bn_dropout
 from .layer import GATConv
 
 
@@ -74,6 +75,9 @@ class GAT(nn.Module):
         self.epochs, self.patience, self.num_classes = epochs, patience, num_classes
         self.verbose = verbose
         self.checkpoint_path = "best_model.pth"
+        # elu -> bn -> dropout between the layers as one fused op (gat_amd/glue.py) instead of
+        # three stock ones; same modules, same state_dict
+        self.fused_glue = True
         self.conv1 = GATConv(num_features, hidden_dim, heads=8, dropout=dropout)
         self.bn1 = nn.BatchNorm1d(hidden_dim * 8)
         self.conv2 = GATConv(hidden_dim * 8, hidden_dim, heads=8, dropout=dropout)
@@ -101,10 +105,15 @@ class GAT(nn.Module):
         data = self._on_device(data)
         x, edge_index = data.x, data.edge_index
         x = self.dropout(x)
-        x = self.bn1(F.elu(self.conv1(x, edge_index)))
-        x = self.dropout(x)
-        x = self.bn2(F.elu(self.conv2(x, edge_index)))
-        x = self.dropout(x)
+        if self.fused_glue:
+            p = self.dropout.p
+            x = elu_bn_dropout(self.conv1(x, edge_index), self.bn1, p, self.training)
+            x = elu_bn_dropout(self.conv2(x, edge_index), self.bn2, p, self.training)
+        else:
+            x = self.bn1(F.elu(self.conv1(x, edge_index)))
+            x = self.dropout(x)
+            x = self.bn2(F.elu(self.conv2(x, edge_index)))
+            x = self.dropout(x)
         return F.log_softmax(self.conv3(x, edge_index), dim=1)
 
     def _scores(self, out, y, loss):

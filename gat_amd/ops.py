@@ -131,12 +131,32 @@ def add_dst_term(d_hp: Tensor, d_a_dst: Tensor, att_dst: Tensor, heads: int, cha
 
 
 # ------------------------------------------------------------------ input-side aggregation
-def inagg_supported(in_features: int, heads: int, channels: int) -> bool:
-    """True when the input-side aggregation kernels cover this layer AND it pays: an x row is
-    narrower than a projected row (F < H*Cp)."""
+def inagg_supported(in_features: int, heads: int, channels: int, edges_per_node: float = None
+                    ) -> bool:
+    """True when the input-side aggregation kernels cover this layer AND it pays.  Bytes per
+    destination node of one forward + backward (fp32): the edge kernels gather a row per edge
+    in each direction; the input-side path also writes/reads the per-head aggregates Z and q
+    [H*Fp] six times, the projected-row path its [Dp] tables about ten times.  Without a degree
+    (edges_per_node None) the test is the row width alone."""
+    dp = heads * padded_channels(channels)
     shape = _lib.Shape(0, in_features, heads, channels)
-    return (in_features < heads * padded_channels(channels)
-            and bool(_lib.lib().gatmi_inagg_supported(C.byref(shape))))
+    if in_features >= dp or not bool(_lib.lib().gatmi_inagg_supported(C.byref(shape))):
+        return False
+    if edges_per_node is None:
+        return True
+    # float4 slots per lane of the edge kernels (inagg.hip make_in_geo): beyond 2 the per-edge
+    # arithmetic, not the bytes, decides, and the projected-row kernels (1 slot) win
+    # (products-shaped 100 -> 8x30: 8.4 ms against 5.8 ms)
+    h2 = 1 << (heads - 1).bit_length()
+    lph = padded_channels(in_features) // 4
+    lh = min(64 // h2, 1 << (lph - 1).bit_length())
+    if -(-lph // lh) > 2:
+        return False
+    fp = padded_channels(in_features)
+    fs = fp + padded_channels(heads)
+    cost_in = 2 * edges_per_node * fs + 6 * heads * fp
+    cost_rows = 2 * edges_per_node * dp + 10 * dp
+    return cost_in < cost_rows
 
 
 def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, heads: int,

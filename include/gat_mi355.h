@@ -243,6 +243,40 @@ int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const float *z, 
                     const float *grad_out, float *d_weight, float *d_att_src, float *d_att_dst,
                     float *d_bias, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- Inter-layer glue of the reference's network, fused: F.elu -> BatchNorm1d -> Dropout
+ * between two GAT layers (/root/reference/gat/model.py:40-42 and :43-45; SURVEY 8a row a12,
+ * 8f rank 1).  y = dropout(batch_norm(elu(x))).  torch.nn.BatchNorm1d semantics: training
+ * normalises with the batch's biased variance and updates running_mean / running_var (the
+ * latter with the unbiased variance) by `momentum`; eval uses the running statistics.  The
+ * dropout mask is the counter hash (seed, row, column), active only in training. */
+typedef struct gatmi_glue {
+    int64_t rows;          /* N < 2^32 */
+    int32_t cols;          /* D <= 1024 */
+    int32_t training;
+    float eps;             /* BatchNorm1d eps (1e-5)                                   */
+    float momentum;        /* BatchNorm1d momentum (0.1)                               */
+    float dropout_p;       /* nn.Dropout p (model.py:31), [0, 1)                       */
+    int32_t _pad;
+    uint64_t seed;
+    const float *gamma;    /* BatchNorm weight [D]                                     */
+    const float *beta;     /* BatchNorm bias [D]                                       */
+    float *running_mean;   /* [D], updated in place in training (NULL: not tracked)    */
+    float *running_var;    /* [D]                                                      */
+} gatmi_glue;
+
+size_t gatmi_glue_workspace_bytes(int cols);
+/*   x [N, D] -> y [N, D];  save_mean, save_rstd [D]: the statistics used (for the backward) */
+int gatmi_glue_fwd(const gatmi_glue *g, const float *x, float *y, float *save_mean,
+                   float *save_rstd, void *ws, size_t ws_bytes, void *stream);
+/*   grad_y [N, D] -> grad_x [N, D], grad_gamma [D], grad_beta [D] (NULL to skip) */
+int gatmi_glue_bwd(const gatmi_glue *g, const float *x, const float *grad_y,
+                   const float *save_mean, const float *save_rstd, float *grad_x,
+                   float *grad_gamma, float *grad_beta, void *ws, size_t ws_bytes, void *stream);
+/* The keep-mask of (seed, row, column), bytes [N, D] -- what nn.Dropout's Bernoulli draw is to
+ * the reference; for inspection and tests. */
+int gatmi_glue_mask(int64_t rows, int32_t cols, float dropout_p, uint64_t seed, uint8_t *mask,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,3 +296,15 @@ def algorithmic_bytes(num_nodes: int, num_edges: int, heads: int, channels: int)
     fwd = num_edges * (4 * d + 4 * heads + 4) + num_nodes * (4 * d + 12 * heads + 4)
     bwd = num_edges * (8 * d + 16 * heads + 12) + num_nodes * (8 * d + 16 * heads)
     return dict(fwd=fwd, bwd=bwd, total=fwd + bwd)
+
+
+def elu_bn_dropout_ref(x, bn, mask=None, p=0.0):
+    """The reference's glue between two layers, /root/reference/gat/model.py:40-42 (and :43-45):
+    x = F.elu(x); x = bn(x); x = dropout(x) -- with the dropout's Bernoulli draw replaced by an
+    explicit keep-mask (the same trick as the attention dropout).  `bn` is a torch
+    nn.BatchNorm1d in the wanted mode; its running statistics are updated as the module does."""
+    import torch.nn.functional as F
+    y = bn(F.elu(x))
+    if bn.training and p > 0.0 and mask is not None:
+        y = y * mask.to(y.dtype) / (1.0 - p)
+    return y
