@@ -384,21 +384,43 @@ __global__ __launch_bounds__(256, 1) void gemm_kres_kernel(const float *__restri
         asm volatile("" : "+v"(boff));           // OFFSET (laundering the pointer itself makes it
         const float *blt = bl + boff;            // generic: flat loads that wait on vmcnt too)
 
-        for (int j = 0; j < KC; ++j) {
+        // software pipeline over the contraction steps: the operands of step j + 1 (one
+        // ds_read_b128 of A, 4 NT floats of B) are requested before the MFMAs of step j issue
+        auto a_read = [&](int j) {
             const int c = 2 * j + half;
-            f32x4 a4;
-            {
-                const int cc = c < nf4 ? c : 0;   // the pad chunk multiplies zero rows of B
-                const unsigned addr = (unsigned)(uintptr_t)(
-                    (const __attribute__((address_space(3))) char *)(at + (SWZ ? (cc ^ (l & 15)) : cc) * 16));
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a4) : "v"(addr) : "memory");
-            }
+            const int cc = c < nf4 ? c : 0;       // the pad chunk multiplies zero rows of B
+            const unsigned addr = (unsigned)(uintptr_t)(
+                (const __attribute__((address_space(3))) char *)(at + (SWZ ? (cc ^ (l & 15)) : cc) * 16));
+            f32x4 v;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+            return v;
+        };
+        f32x4 a4 = a_read(0);
+        float b4[4][NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b4[i][nt] = blt[i * LDB + nt * 32];
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4));
+        for (int j = 0; j < KC; ++j) {
+            const int jn = j + 1 < KC ? j + 1 : j;
+            f32x4 an = a_read(jn);
+            float bn[4][NT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[i][nt] = blt[(8 * jn + i) * LDB + nt * 32];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        a4[i], blt[(8 * j + i) * LDB + nt * 32], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b4[i][nt], acc[nt], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an));
+            a4 = an;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b4[i][nt] = bn[i][nt];
         }
         const long long row0 = t * 32;
         const bool full = row0 + 32 <= M;        // one branch per tile, not one per store
