@@ -441,6 +441,164 @@ __global__ __launch_bounds__(256, 1) void gemm_kres_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------
+// The same product with B in REGISTERS.  The LDS kernel above is latency bound: 39 % of its wave
+// cycles sit at the tile wait (profiles/r1/pmc_gemm_waits.txt) because B takes 32 KB of LDS and
+// the rest holds only two tiles per wave -- one in flight while the other is multiplied, ~50 KB
+// per CU, a quarter of what a 7-TB/s stream needs.  One wave per SIMD owns 512 registers and uses
+// 100: here each lane keeps its B operands (k = 8j + 4 half + i, column nt*32 + l: KC*4*NT
+// floats, at most 128) for the lifetime of the block, the contraction is unrolled over KC
+// steps, and all 160 KB of LDS are tile buffers: NBUF = 3-4 per wave, two or three in flight.
+// ---------------------------------------------------------------------------------
+template <int NT, int KC, bool SWZ>
+__global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restrict__ A, int lda,
+                                                           const float *__restrict__ B, int ldb,
+                                                           int b_kmajor, float *__restrict__ C,
+                                                           int ldc, int M, int Nn, int K, int nf4,
+                                                           int nbuf, const GemmBatch gb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int batch = blockIdx.y;
+    A += (size_t)batch * gb.sA;
+    B += (size_t)batch * gb.sB;
+    C += (size_t)batch * gb.sC;
+    const float *bias = gb.bias ? gb.bias + (size_t)batch * gb.sBias : nullptr;
+    const int lane = threadIdx.x & 63, l = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    // operands and bias are fetched (and waited for: the empty asm uses them) before any DMA is
+    // in flight -- a later first use would make hipcc drain the DMA queue with vmcnt(0)
+    float breg[KC][4][NT], bv[NT];
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int k = 8 * j + 4 * half + i, n = nt * 32 + l;
+                float v = 0.f;
+                if (k < K && n < Nn) v = b_kmajor ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
+                breg[j][i][nt] = v;
+            }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cn = nt * 32 + l;
+        bv[nt] = (bias && cn < Nn) ? bias[cn] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(breg[j][i][nt]));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bv[nt]));
+
+    const unsigned rowb = (unsigned)nf4 * 16u, tileb = 32u * rowb;
+    char *abuf = smem + (size_t)wave * nbuf * tileb;
+    const int rpi = 64 / nf4;                   // rows per DMA instruction
+    const int ninstr = (32 + rpi - 1) / rpi;
+    const int er = lane / nf4, ep = lane - er * nf4;
+    const bool dma_on = er < rpi;
+    const long long ntiles = ((long long)M + 31) / 32;
+    const long long tstride = (long long)gridDim.x * 4;
+    // DMA source of instruction i = (wave-uniform tile base + i * rows-per-instruction) + a 32-bit
+    // lane offset: scalar address arithmetic, no 64-bit vector multiplies in the tile loop.  Only
+    // the last, partial tile clamps its rows.
+    const unsigned lane_off = ((unsigned)er * (unsigned)lda + (unsigned)ep * 4u) * 4u;
+    const unsigned step_off = (unsigned)rpi * (unsigned)lda * 4u;
+    auto issue = [&](long long tile, int buf) {
+        char *dst = abuf + buf * tileb;
+        const char *src = reinterpret_cast<const char *>(A + tile * 32 * lda);   // uniform
+        const bool whole = __builtin_amdgcn_readfirstlane((int)(tile * 32 + 32 <= M)) != 0;
+        if (whole && (32 % rpi) == 0) {
+            for (int i = 0; i < ninstr; ++i) {
+                unsigned off = lane_off;
+                if (SWZ) off = ((unsigned)er * (unsigned)lda + (unsigned)((ep ^ ((i * rpi + er) & 15)) * 4)) * 4u;
+                if (dma_on) kres_dma16(src + (size_t)i * step_off + off, dst + (unsigned)(i * rpi) * rowb);
+            }
+        } else {
+            for (int i = 0; i < ninstr; ++i) {
+                const int rl = i * rpi + er;                        // row inside the tile
+                long long row = tile * 32 + (rl < 32 ? rl : 31);
+                row = row < M ? row : (long long)M - 1;
+                const int piece = SWZ ? (ep ^ (rl & 15)) : ep;
+                const float *g = A + row * lda + piece * 4;
+                if (dma_on && rl < 32) kres_dma16(g, dst + (unsigned)(i * rpi) * rowb);
+            }
+        }
+    };
+    // A wave's vector-memory operations: ... stores(t-1), DMA(t+nbuf-1) | wait(t), MFMA(t),
+    // stores(t), DMA(t+nbuf) ...  Loads retire in order, so "at most (tiles issued after t) *
+    // ninstr operations outstanding" means tile t has landed whatever the stores do.
+    long long t = (long long)blockIdx.x * 4 + wave;
+    for (int b = 0; b < nbuf; ++b)
+        if (t + b * tstride < ntiles) issue(t + b * tstride, b);
+    int buf = 0;
+    long long after = t < ntiles ? (ntiles - 1 - t) / tstride : 0;   // this wave's tiles after t
+    for (; t < ntiles; t += tstride, --after) {
+        kres_wait_vm((int)(after < nbuf - 1 ? after : nbuf - 1) * ninstr);
+        const char *at = abuf + buf * tileb + (unsigned)l * rowb;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        auto a_read = [&](int j) {
+            const int c = 2 * j + half;
+            const int cc = c < nf4 ? c : 0;       // a pad chunk meets zero operands of B
+            const unsigned addr = (unsigned)(uintptr_t)(
+                (const __attribute__((address_space(3))) char *)(at + (SWZ ? (cc ^ (l & 15)) : cc) * 16));
+            f32x4 v;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+            return v;
+        };
+        f32x4 a4 = a_read(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4));
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            f32x4 an = a_read(j + 1 < KC ? j + 1 : j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], breg[j][i][nt], acc[nt], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an));
+            a4 = an;
+        }
+        const long long row0 = t * 32;
+        if (__builtin_amdgcn_readfirstlane((int)(row0 + 32 <= M))) {
+            // whole tile: uniform row base + 32-bit lane offset, no per-store predicate
+            char *cb = reinterpret_cast<char *>(C + row0 * ldc);
+            const unsigned ldcb = (unsigned)ldc * 4u;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cn = nt * 32 + l;
+                const unsigned lo = (unsigned)(4 * half) * ldcb + (unsigned)cn * 4u;
+                if (cn < gb.n_store) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned dr = (r & 3) + 8 * (r >> 2);
+                        *reinterpret_cast<float *>(cb + (size_t)(dr * ldcb) + lo) = acc[nt][r] + bv[nt];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cn = nt * 32 + l;
+                if (cn < gb.n_store) {
+                    float *cp = C + (size_t)(row0 + 4 * half) * ldc + cn;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (row0 + 4 * half + dr < M) cp[(size_t)dr * ldc] = acc[nt][r] + bv[nt];
+                    }
+                }
+            }
+        }
+        if (t + (long long)nbuf * tstride < ntiles) issue(t + (long long)nbuf * tstride, buf);
+        buf = buf + 1 < nbuf ? buf + 1 : 0;
+    }
+}
+
 static size_t kres_dyn_lds(int nf4) { return (size_t)4 * 2 * 32 * nf4 * 16; }
 static size_t kres_lds_bytes(int nf4, int NT) {
     return (size_t)128 * NT * 32 * 4 + kres_dyn_lds(nf4);
@@ -487,6 +645,55 @@ static void kres_launch(const GemmDesc &d, int nf4, hipStream_t st) {
                        d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, gb);
 }
 
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+    }
+    return cus;
+}
+
+template <int NT, int KC, bool SWZ>
+static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
+    const size_t tileb = (size_t)32 * nf4 * 16;
+    int nbuf = (int)((160 * 1024) / (4 * tileb));
+    nbuf = nbuf > 4 ? 4 : nbuf;
+    const size_t lds = (size_t)4 * nbuf * tileb;
+    static size_t dyn_cap = 0;   // dynamic LDS beyond 64 KiB has to be granted per kernel
+    if (lds > dyn_cap) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kreg_kernel<NT, KC, SWZ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            dyn_cap = lds;
+    }
+    long long bx = ((long long)device_cus() + d.nbatch - 1) / d.nbatch;   // one resident set
+    const long long need = (((long long)d.M + 31) / 32 + 3) / 4;
+    if (bx > need) bx = need;
+    if (bx < 1) bx = 1;
+    GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, 1, d.n_store, nullptr};
+    hipLaunchKernelGGL((gemm_kreg_kernel<NT, KC, SWZ>), dim3((unsigned)bx, d.nbatch), dim3(256), lds, st,
+                       d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, nbuf, gb);
+}
+
+// B-in-registers variant: at most 128 operand registers per lane, at least 3 tile buffers per wave
+template <int NT>
+static bool kreg_dispatch(const GemmDesc &d, int nf4, hipStream_t st) {
+    static const char *env = getenv("GATMI_KREG");   // A/B switch: 0 = B in LDS
+    if (env && env[0] == '0') return false;
+    const int kc = (nf4 + 1) / 2;
+    if ((size_t)4 * 3 * 32 * nf4 * 16 > 160 * 1024) return false;
+    if (nf4 == 16) { kreg_launch<NT, 8, true>(d, nf4, st); return true; }
+    if (kc <= 4) { kreg_launch<NT, 4, false>(d, nf4, st); return true; }
+    if (kc <= 8) { kreg_launch<NT, 8, false>(d, nf4, st); return true; }
+    if constexpr (NT <= 2) {
+        if (kc <= 13) { kreg_launch<NT, 13, false>(d, nf4, st); return true; }
+        if (kc <= 16) { kreg_launch<NT, 16, false>(d, nf4, st); return true; }
+    }
+    return false;
+}
+
 int launch_kres(const GemmDesc &d0, hipStream_t st) {
     GemmDesc d = d0;
     if (d.n_store < d.Nn) d.n_store = d.Nn;
@@ -495,9 +702,13 @@ int launch_kres(const GemmDesc &d0, hipStream_t st) {
     GATMI_REQUIRE(kres_covers(d), "K-resident GEMM does not cover this product");
     const int nf4 = (d.a_kpad > d.K ? d.a_kpad : d.K) / 4;
     const bool swz = nf4 == 16;
-    if (d.n_store <= 32) swz ? kres_launch<1, true>(d, nf4, st) : kres_launch<1, false>(d, nf4, st);
-    else if (d.n_store <= 64) swz ? kres_launch<2, true>(d, nf4, st) : kres_launch<2, false>(d, nf4, st);
-    else swz ? kres_launch<4, true>(d, nf4, st) : kres_launch<4, false>(d, nf4, st);
+    if (d.n_store <= 32) {
+        if (!kreg_dispatch<1>(d, nf4, st)) swz ? kres_launch<1, true>(d, nf4, st) : kres_launch<1, false>(d, nf4, st);
+    } else if (d.n_store <= 64) {
+        if (!kreg_dispatch<2>(d, nf4, st)) swz ? kres_launch<2, true>(d, nf4, st) : kres_launch<2, false>(d, nf4, st);
+    } else {
+        if (!kreg_dispatch<4>(d, nf4, st)) swz ? kres_launch<4, true>(d, nf4, st) : kres_launch<4, false>(d, nf4, st);
+    }
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
