@@ -598,6 +598,119 @@ __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
 }
 
 // ---------------------------------------------------------------------------------
+// The same pass with the per-(edge, head) scalar chain hoisted out of the row loop.  In the
+// kernel above every lane of a head group repeats  u -> LeakyReLU -> exp -> keep -> slope  for
+// each edge (about 22 of the ~35 vector instructions an edge costs; the pass is VALU-issue
+// bound).  Here lane (head h, sub-lane s) does that once for edge s, s + LH, ... of the chunk --
+// one (edge, head) pair per lane, a_src gathered as one dword per lane -- and leaves
+//   c1 = alpha~ * slope,   c0 = -alpha * S * slope        (d_u = c1 * <q, x_j> + c0)
+// in a wave-private LDS table; the row loop then reads the pair of its edge (one ds_read_b64,
+// broadcast within the head group) and is left with the dot, the butterfly and the FMAs.
+// H2 <= 8 (table of 64 * H2 * 8 bytes per wave).
+// ---------------------------------------------------------------------------------
+constexpr int kBwd2MaxH2 = 8;
+
+template <int LH_T, int G, int T>
+__global__ __launch_bounds__(256) void inagg_bwd2_kernel(const InArgs A, int H2) {
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 2);
+    __shared__ f2 cs_all[4][64 * kBwd2MaxH2];
+    INAGG_PROLOGUE
+    f2 *cs = cs_all[threadIdx.x >> 6] + gbase * H2;      // this group's table: [edge][H2]
+    (void)aoff;
+    f4 ys[T], yd[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) ys[t] = yd[t] = zero4();
+    INAGG_ITEM_LOOP
+        (void)slot;
+        f4 q4[T];
+        f2 s2 = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            q4[t] = ok[t] ? ldv4(A.q + (size_t)row * HF + roff[t]) : zero4();
+            const f4 z4 = ok[t] ? ldv4(A.zin + (size_t)row * HF + roff[t]) : zero4();
+            pk_dot4(s2, q4[t], z4);
+        }
+        const float S = head_sum<LH_T>(s2.x + s2.y, lh);
+        const float lse_i = A.lsein[(size_t)row * A.H + head];
+        float dad = 0.f;
+        for (int c = beg; c < end; c += G) {
+            const int n = min(G, end - c);
+            const int cl = min(lig, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](f4(&v)[U][T], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) v[u][t] = ldv4_row<G>(A.xs, j, A.Fs, offb[t]);
+                }
+            };
+            f4 va[U][T], vb[U][T];
+            load(va, 0);
+            // the chain, one (edge, head) pair per lane
+            for (int e0 = 0; e0 < n; e0 += lh) {
+                const int e = e0 + sl;
+                const int ec = min(e, n - 1);
+                const int js = __shfl(cj, gbase + ec, 64);
+                const unsigned sb = (unsigned)__shfl(kb, gbase + ec, 64);
+                const float as = A.xs[(size_t)js * A.Fs + A.Fp + head];
+                const float uu = as + adi;
+                const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                const float alpha = e < n ? exp_fast(uu * slope - lse_i) : 0.f;
+                const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
+                if (hok) cs[e * H2 + head_raw] = f2{at * slope, -alpha * S * slope};
+            }
+            auto reduce = [&](const f4(&v)[U][T], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    f2 d = {0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < T; ++t) pk_dot4(d, v[u][t], q4[t]);
+                    const float d2 = head_sum<LH_T>(d.x + d.y, lh);
+                    const f2 cc = cs[min(k0 + u, n - 1) * H2 + head];
+                    const float du = k0 + u < n ? fmaf(d2, cc.x, cc.y) : 0.f;
+                    dad += du;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) pk_fma4(ys[t], du, v[u][t]);
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 2 * U) {
+                load(vb, k0 + U);
+                reduce(va, k0);
+                load(va, k0 + 2 * U);
+                reduce(vb, k0 + U);
+            }
+        }
+        // d_wd += (sum of the row's d_u) * x_i
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f4 xi = ok[t] ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + (offb[t] >> 2)) : zero4();
+            pk_fma4(yd[t], dad, xi);
+        }
+    }
+    if constexpr (G < 64) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            for (int o = G; o < 64; o <<= 1)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ys[t][k] += __shfl_xor(ys[t][k], o, 64);
+                    yd[t][k] += __shfl_xor(yd[t][k], o, 64);
+                }
+    }
+    if (lane < G) {
+        float *dst = A.part_y + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 * HF;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (ok[t]) {
+                stv4(dst + roff[t], ys[t]);
+                stv4(dst + HF + roff[t], yd[t]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Small kernels around the two passes
 // ---------------------------------------------------------------------------------
 // wsd[k][h*Fp + f] = sum_c W[(h*C + c), f] * att_k[h*C + c]  (k = 0: att_src, 1: att_dst), pad = 0
@@ -792,10 +905,17 @@ static bool make_in_geo(const gatmi_shape &s, InGeo *g) {
 
 enum InKind { IN_FWD, IN_BWD };
 
+static bool bwd2_on() {   // A/B switch: GATMI_BWD2=0 runs the kernel with the chain in the row loop
+    static const char *env = getenv("GATMI_BWD2");
+    return !(env && env[0] == '0');
+}
+
 template <int LH_T, int G, int T>
 static void in_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
     if (k == IN_FWD)
         hipLaunchKernelGGL((inagg_fwd_kernel<LH_T, G, T>), dim3(grid), dim3(256), 0, st, A);
+    else if (bwd2_on() && next_pow2(A.H) <= kBwd2MaxH2)
+        hipLaunchKernelGGL((inagg_bwd2_kernel<LH_T, G, T>), dim3(grid), dim3(256), 0, st, A, next_pow2(A.H));
     else
         hipLaunchKernelGGL((inagg_bwd_kernel<LH_T, G, T>), dim3(grid), dim3(256), 0, st, A);
 }
