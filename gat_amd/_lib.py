@@ -98,6 +98,11 @@ SYMBOLS = {
                                  C.c_void_p]),
     "gatmi_glue_mask": (C.c_int, [C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
                                   C.c_void_p]),
+    "gatmi_tail_workspace_bytes": (C.c_size_t, []),
+    "gatmi_tail_fwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_tail_bwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "gatmi_inagg_supported": (C.c_int, [C.POINTER(Shape)]),
     "gatmi_inagg_z_floats": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_inagg_xs_floats": (C.c_size_t, [C.POINTER(Shape)]),

@@ -90,6 +90,53 @@ def elu_bn_dropout(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed
                          bn.momentum, p if training else 0.0, seed)
 
 
+class _TailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        lib, dev = _lib.lib(), logits.device
+        logits, target = logits.contiguous(), target.contiguous()
+        n, k = logits.shape
+        with torch.cuda.device(dev):
+            logp = torch.empty_like(logits)
+            stats = torch.empty(2, dtype=torch.float32, device=dev)
+            ws = torch.empty(int(lib.gatmi_tail_workspace_bytes()), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gatmi_tail_fwd(n, k, logits.data_ptr(), target.data_ptr(), logp.data_ptr(),
+                                          stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "gatmi_tail_fwd")
+        ctx.save_for_backward(logp, target, stats)
+        return logp, stats[0]
+
+    @staticmethod
+    def backward(ctx, grad_logp, grad_loss):
+        logp, target, stats = ctx.saved_tensors
+        lib, dev = _lib.lib(), logp.device
+        n, k = logp.shape
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(logp)
+            gl = None if grad_loss is None else grad_loss.to(torch.float32).contiguous()
+            gp = None if grad_logp is None else grad_logp.contiguous()
+            _lib.check(lib.gatmi_tail_bwd(n, k, logp.data_ptr(), target.data_ptr(), stats.data_ptr(),
+                                          None if gl is None else gl.data_ptr(),
+                                          None if gp is None else gp.data_ptr(), gx.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "gatmi_tail_bwd")
+        return gx, None
+
+
+def log_softmax_nll(logits: Tensor, target: Tensor):
+    """(F.log_softmax(logits, dim=1), F.nll_loss(of that, target)) -- /root/reference/gat/model.py:47
+    and :53 -- in one pass forward and one backward (gat_amd/csrc/tail.hip).  GPU only, fp32
+    logits [N, classes <= 256], int64 targets."""
+    if not logits.is_cuda or not target.is_cuda:
+        raise RuntimeError("gat_amd.glue runs on the GPU only (no CPU fallback)")
+    if logits.dim() != 2 or target.dim() != 1 or target.size(0) != logits.size(0):
+        raise ValueError(f"logits must be [N, K] and target [N], got {tuple(logits.shape)}, {tuple(target.shape)}")
+    if logits.dtype != torch.float32 or target.dtype != torch.int64:
+        raise TypeError(f"logits must be float32 and target int64, got {logits.dtype}, {target.dtype}")
+    if logits.size(1) > 256:
+        raise ValueError("log_softmax_nll covers up to 256 classes")
+    return _TailFn.apply(logits, target)
+
+
 def dropout_mask(rows: int, cols: int, p: float, seed: int, device) -> Tensor:
     """The keep-mask elu_bn_dropout uses for (p, seed), as a bool tensor [rows, cols]."""
     mask = torch.empty(rows, cols, dtype=torch.uint8, device=device)

@@ -1,7 +1,8 @@
 """The reference's network and training loop (/root/reference/gat/model.py:18-133) on
 gat_amd.GATConv: same constructor, forward(data), train_model(train, val) -> Metrics and
 test_model(data).  The three layer calls are the HIP hot path; ELU / BatchNorm / dropout /
-log_softmax / nll_loss / the optimizer stay stock PyTorch-ROCm ops.
+the optimizer stay stock PyTorch-ROCm ops; ELU/BatchNorm/dropout and log_softmax/nll_loss
+run fused (gat_amd/glue.py; `fused_glue = False` restores the stock ops).
 
 Differences a caller can see, all forced by the move to a GPU or to torch 2.10:
   * the model lives on the GPU (`device`, default cuda:LOCAL_RANK) and moves `data` there
@@ -24,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .data import Data, Metrics
-from .glue import elu_bn_dropout
+from .glue import elu_bn_dropout, log_softmax_nll
 from .layer import GATConv
 
 
@@ -101,8 +102,7 @@ class GAT(nn.Module):
             self._resident[id(data)] = hit
         return hit[1]
 
-    def forward(self, data):
-        data = self._on_device(data)
+    def _logits(self, data):
         x, edge_index = data.x, data.edge_index
         x = self.dropout(x)
         if self.fused_glue:
@@ -114,7 +114,17 @@ class GAT(nn.Module):
             x = self.dropout(x)
             x = self.bn2(F.elu(self.conv2(x, edge_index)))
             x = self.dropout(x)
-        return F.log_softmax(self.conv3(x, edge_index), dim=1)
+        return self.conv3(x, edge_index)
+
+    def forward(self, data):
+        return F.log_softmax(self._logits(self._on_device(data)), dim=1)
+
+    def _out_and_loss(self, data):
+        """(log-probabilities, mean nll loss): model.py:52-53, fused when `fused_glue`."""
+        if self.fused_glue:
+            return log_softmax_nll(self._logits(data), data.y)
+        out = self(data)
+        return out, F.nll_loss(out, data.y)
 
     def _scores(self, out, y, loss):
         preds = out.argmax(dim=1)
@@ -126,8 +136,7 @@ class GAT(nn.Module):
         data = self._on_device(data)
         self.train()
         self.optimizer.zero_grad()
-        out = self(data)
-        loss = F.nll_loss(out, data.y)
+        out, loss = self._out_and_loss(data)
         loss.backward()
         self.optimizer.step()
         stats, _ = self._scores(out.detach(), data.y, loss.detach())
@@ -137,8 +146,8 @@ class GAT(nn.Module):
         data = self._on_device(data)
         self.eval()
         with torch.no_grad():
-            out = self(data)
-            stats, cm = self._scores(out, data.y, F.nll_loss(out, data.y))
+            out, loss = self._out_and_loss(data)
+            stats, cm = self._scores(out, data.y, loss)
         return stats + (cm.numpy(),)
 
     def train_model(self, train_data, val_data) -> Metrics:

@@ -277,6 +277,20 @@ int gatmi_glue_bwd(const gatmi_glue *g, const float *x, const float *grad_y,
 int gatmi_glue_mask(int64_t rows, int32_t cols, float dropout_p, uint64_t seed, uint8_t *mask,
                     void *stream);
 
+/* ---- log_softmax + nll_loss tail ------------------------------------------------------------
+ * Replaces  F.log_softmax(x, dim=1)  (/root/reference/gat/model.py:47) and  F.nll_loss(out, y)
+ * (model.py:53, mean reduction) and their autograd backward.  logits, logp: float32
+ * [rows, classes], classes <= 256; target: int64 [rows] (values outside [0, classes) are not
+ * counted, as torch's ignore_index).  loss_stats: float32 [2] = {mean loss, 1 / counted rows}. */
+size_t gatmi_tail_workspace_bytes(void);
+int gatmi_tail_fwd(int64_t rows, int32_t classes, const float *logits, const int64_t *target,
+                   float *logp, float *loss_stats, void *ws, size_t ws_bytes, void *stream);
+/*   grad_loss: device scalar (NULL = 0); grad_logp [rows, classes] or NULL: a gradient arriving
+ *   at the log-probabilities from elsewhere -> grad_logits [rows, classes] */
+int gatmi_tail_bwd(int64_t rows, int32_t classes, const float *logp, const int64_t *target,
+                   const float *loss_stats, const float *grad_loss, const float *grad_logp,
+                   float *grad_logits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

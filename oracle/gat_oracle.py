@@ -308,3 +308,11 @@ def elu_bn_dropout_ref(x, bn, mask=None, p=0.0):
     if bn.training and p > 0.0 and mask is not None:
         y = y * mask.to(y.dtype) / (1.0 - p)
     return y
+
+
+def log_softmax_nll_ref(logits, target):
+    """(log-probabilities, mean nll loss) as /root/reference/gat/model.py:47 and :53 compute them
+    (stock CPU torch ops; test infrastructure like the rest of this file)."""
+    import torch.nn.functional as F
+    logp = F.log_softmax(logits, dim=1)
+    return logp, F.nll_loss(logp, target)

@@ -108,3 +108,44 @@ def test_model_with_fused_glue_matches_stock_glue(cuda):
         atol = scale * max(float(ref.abs().max()), 1e-6)
         torch.testing.assert_close(pa.grad, ref, rtol=2e-5, atol=atol, msg=lambda m: f"{na}: {m}")
     close(a.bn1.running_var, b.bn1.running_var, "bn1.running_var")
+
+
+# ---- log_softmax + nll_loss tail (gat_amd/csrc/tail.hip, C ABI gatmi_tail_*) ------------------
+@pytest.mark.parametrize("n,k", [(1000, 2), (1000, 7), (169, 40), (5000, 47), (3, 1), (70000, 40),
+                                 (513, 64), (300, 100), (64, 256), (1, 5)])
+def test_tail_matches_torch(cuda, n, k):
+    """Forward log-probabilities and mean loss, backward through the loss alone and through
+    loss + an extra gradient on the log-probabilities, against stock CPU torch ops."""
+    from gat_amd.glue import log_softmax_nll
+    g = torch.Generator().manual_seed(n * 131 + k)
+    x = torch.randn(n, k, generator=g) * 3.0
+    y = torch.randint(0, k, (n,), generator=g)
+    extra = torch.randn(n, k, generator=g)
+    for with_extra in (False, True):
+        xr = x.clone().requires_grad_(True)
+        logp_r, loss_r = O.log_softmax_nll_ref(xr, y)
+        (loss_r * 1.7 + ((logp_r * extra).sum() if with_extra else 0.0)).backward()
+        xd = x.to(cuda).requires_grad_(True)
+        logp_d, loss_d = log_softmax_nll(xd, y.to(cuda))
+        (loss_d * 1.7 + ((logp_d * extra.to(cuda)).sum() if with_extra else 0.0)).backward()
+        close(logp_d, logp_r, "logp")
+        torch.testing.assert_close(loss_d.cpu(), loss_r.detach(), rtol=2e-6, atol=1e-7)
+        close(xd.grad, xr.grad, "d_logits", floor=float(extra.abs().max()) if with_extra else 1.7 / n)
+
+
+def test_tail_ignores_out_of_range_targets(cuda):
+    """torch's ignore_index (-100): not counted in the mean, zero gradient row."""
+    from gat_amd.glue import log_softmax_nll
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(200, 6, generator=g)
+    y = torch.randint(0, 6, (200,), generator=g)
+    y[::7] = -100
+    xr = x.clone().requires_grad_(True)
+    _, loss_r = O.log_softmax_nll_ref(xr, y)
+    loss_r.backward()
+    xd = x.to(cuda).requires_grad_(True)
+    _, loss_d = log_softmax_nll(xd, y.to(cuda))
+    loss_d.backward()
+    torch.testing.assert_close(loss_d.cpu(), loss_r.detach(), rtol=2e-6, atol=1e-7)
+    close(xd.grad, xr.grad, "d_logits", floor=1.0 / 200)
+    assert float(xd.grad[::7].abs().max()) == 0.0
