@@ -107,5 +107,6 @@ int launch_gemm(const GemmDesc &d, hipStream_t st);
 // tall row-major A (16-byte aligned rows, K <= 128), small B kept in LDS: see project.hip
 bool kres_covers(const GemmDesc &d);
 int launch_kres(const GemmDesc &d, hipStream_t st);
+int device_cus();   // CUs of the current device (256 when it cannot be queried)
 
 }  // namespace gatmi

@@ -799,6 +799,132 @@ __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const f
 }
 
 // dst[col] = sum of nrows partial rows, fixed order.  One block per (job, 16 columns).
+// ---------------------------------------------------------------------------------
+// d_W slabs  slab[split][h] = g[rows, h, :]^T Z[rows, h, :]  without LDS: the contraction runs
+// over ROWS, so both MFMA operands are coalesced dword loads straight into registers
+// (v_mfma_f32_32x32x2_f32: lane (l, half) supplies A[m = l][k = half] = g[n0 + half][c = l] and
+// B[k = half][n = l] = Z[n0 + half][f = l]).  A wave owns one head and one contiguous row
+// range, keeps the whole [32 CT x 32 NT] result in accumulators and D row pairs of operands
+// in flight; consecutive waves take the heads of the same rows, so a block reads whole rows.
+// The tiled kernel needs LDS staging, barriers and a transposing read for the same product
+// and sits at 46 % waitcnt (profiles/r1/pmc_gemm_waits.txt).  Column sums of g (d_bias) ride
+// on the A operands.
+// ---------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kDwBank = 6;
+
+template <int CT, int NT>
+__global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
+    const float *__restrict__ g, int ldg, const float *__restrict__ z, int ldz, int N, int H, int C,
+    int F, int Fp, int nsplit, int rows_per_split, float *__restrict__ slab, float *__restrict__ gsum) {
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= H * nsplit) return;
+    const int split = w / H, h = w - split * H;
+    const int lane = threadIdx.x & 63, l = lane & 31, half = lane >> 5;
+    const long long n_beg = (long long)split * rows_per_split;
+    const long long n_end = n_beg + rows_per_split < N ? n_beg + rows_per_split : N;
+    const int nrows = n_end > n_beg ? (int)(n_end - n_beg) : 0;
+    const int np = nrows >> 1;                               // whole row pairs; an odd last row below
+    // addresses = wave-uniform row-pair base (scalar registers) + a 32-bit lane offset
+    unsigned go[CT], zo[NT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) go[ct] = (unsigned)(half * ldg + h * C + min(l + 32 * ct, C - 1)) * 4u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) zo[nt] = (unsigned)(half * ldz + h * Fp + min(l + 32 * nt, Fp - 1)) * 4u;
+    const char *gb0 = reinterpret_cast<const char *>(g + (size_t)n_beg * ldg);
+    const char *zb0 = reinterpret_cast<const char *>(z + (size_t)n_beg * ldz);
+    f32x16 acc[CT][NT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][nt][r] = 0.f;
+    float gs[CT], cmask[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        gs[ct] = 0.f;
+        cmask[ct] = l + 32 * ct < C ? 1.f : 0.f;
+    }
+    // Two banks of kDwBank row pairs, one in flight while the other is multiplied (the pattern
+    // the edge kernels use; hipcc counts vmcnt across the loop for it, which it does not for a
+    // per-step ring: it drained every load at the top of each trip).
+    struct Bank {
+        float ga[kDwBank][CT], zb[kDwBank][NT];
+    };
+    auto load = [&](Bank &bk, int p0) {
+#pragma unroll
+        for (int d = 0; d < kDwBank; ++d) {
+            const int pc = p0 + d < np ? p0 + d : np - 1;     // past the end: reload, unused
+            const char *gr = gb0 + (size_t)pc * (size_t)(2 * ldg) * 4;
+            const char *zr = zb0 + (size_t)pc * (size_t)(2 * ldz) * 4;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bk.ga[d][ct] = *reinterpret_cast<const float *>(gr + go[ct]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bk.zb[d][nt] = *reinterpret_cast<const float *>(zr + zo[nt]);
+        }
+    };
+    auto mult = [&](const Bank &bk, int p0) {
+#pragma unroll
+        for (int d = 0; d < kDwBank; ++d) {
+            if (p0 + d < np) {                                // wave-uniform
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float a = bk.ga[d][ct] * cmask[ct];
+                    gs[ct] += a;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bk.zb[d][nt], acc[ct][nt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (np > 0) {
+        Bank ba, bb;
+        load(ba, 0);
+        for (int p0 = 0; p0 < np; p0 += 2 * kDwBank) {
+            load(bb, p0 + kDwBank);
+            mult(ba, p0);
+            load(ba, p0 + 2 * kDwBank);
+            mult(bb, p0 + kDwBank);
+        }
+    }
+    if (nrows & 1) {                                          // the odd last row: k = 1 is zero
+        const size_t row = (size_t)(n_end - 1);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float v = g[row * ldg + h * C + min(l + 32 * ct, C - 1)];
+            const float a = v * (half == 0 ? cmask[ct] : 0.f);
+            gs[ct] += a;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bv = z[row * ldz + h * Fp + min(l + 32 * nt, Fp - 1)];
+                acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ct][nt], 0, 0, 0);
+            }
+        }
+    }
+    float *dst = slab + ((size_t)split * H + h) * C * F;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int f = nt * 32 + l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c < C && f < F) dst[(size_t)c * F + f] = acc[ct][nt][r];
+            }
+        }
+    if (gsum) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float tot = gs[ct] + __shfl_xor(gs[ct], 32, 64);
+            const int c = ct * 32 + l;
+            if (half == 0 && c < C) gsum[((size_t)h * nsplit + split) * C + c] = tot;
+        }
+    }
+}
+
 struct SumJob {
     const float *src;
     float *dst;
@@ -836,45 +962,62 @@ __global__ __launch_bounds__(256) void inagg_finalize_kernel(
     float *d_w, float *d_att_src, float *d_att_dst, float *d_bias) {
     const long long tot = (long long)H * C * F;
     const float *dws = dwsd, *dwd = dwsd + (size_t)H * Fp;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < tot; i += gridDim.x * 256ll) {
-        const int f = (int)(i % F), hc = (int)(i / F), h = hc / C;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int z = 0;
-        for (; z + 3 < nsplit; z += 4) {
-            s0 += slab[(size_t)z * tot + i];
-            s1 += slab[(size_t)(z + 1) * tot + i];
-            s2 += slab[(size_t)(z + 2) * tot + i];
-            s3 += slab[(size_t)(z + 3) * tot + i];
+    // A block sums 64 consecutive outputs; its four waves take the splits z = wave, wave + 4, ...
+    // with eight loads in flight each (the splits number in the hundreds: one thread walking
+    // them all is a chain of memory latencies), and meet in LDS.
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long base = blockIdx.x * 64ll; base < tot; base += gridDim.x * 64ll) {
+        const long long i = base + lane;
+        float s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] = 0.f;
+        if (i < tot)
+            for (int z = wave; z < nsplit; z += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (z + 4 * u < nsplit) s[u] += slab[(size_t)(z + 4 * u) * tot + i];
+            }
+        red[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        __syncthreads();
+        if (wave == 0 && i < tot) {
+            const int f = (int)(i % F), hc = (int)(i / F), h = hc / C;
+            float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            v = fmaf(att_src[hc], dws[h * Fp + f], v);
+            v = fmaf(att_dst[hc], dwd[h * Fp + f], v);
+            if (d_w) d_w[i] = v;
         }
-        for (; z < nsplit; ++z) s0 += slab[(size_t)z * tot + i];
-        float v = (s0 + s1) + (s2 + s3);
-        v = fmaf(att_src[hc], dws[h * Fp + f], v);
-        v = fmaf(att_dst[hc], dwd[h * Fp + f], v);
-        if (d_w) d_w[i] = v;
+        __syncthreads();
     }
     const int HC = H * C;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * HC; i += gridDim.x * 256) {
         const int k = i / HC, hc = i % HC, h = hc / C;
         const float *dv = (k == 0 ? dws : dwd) + h * Fp;
-        float s = 0.f;
-        for (int f = 0; f < F; ++f) s = fmaf(w[(size_t)hc * F + f], dv[f], s);
+        float sacc = 0.f;
+        for (int f = 0; f < F; ++f) sacc = fmaf(w[(size_t)hc * F + f], dv[f], sacc);
         float *dst = k == 0 ? d_att_src : d_att_dst;
-        if (dst) dst[hc] = s;
+        if (dst) dst[hc] = sacc;
     }
-    if (d_bias)   // column sums of grad_out, collected by the d_W GEMM while it staged them
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < HC; i += gridDim.x * 256) {
-            const int h = i / C, c = i % C;
-            const float *src = gsum + (size_t)h * nsplit * C + c;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int z = 0;
-            for (; z + 3 < nsplit; z += 4) {
-                s0 += src[(size_t)z * C];
-                s1 += src[(size_t)(z + 1) * C];
-                s2 += src[(size_t)(z + 2) * C];
-                s3 += src[(size_t)(z + 3) * C];
+    if (d_bias)   // column sums of grad_out, collected by the d_W kernel from its A operands
+        for (int base = blockIdx.x * 64; base < HC; base += gridDim.x * 64) {
+            const int i = base + lane;
+            float s[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] = 0.f;
+            if (i < HC) {
+                const int h = i / C, c = i % C;
+                const float *src = gsum + (size_t)h * nsplit * C + c;
+                for (int z = wave; z < nsplit; z += 32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (z + 4 * u < nsplit) s[u] += src[(size_t)(z + 4 * u) * C];
+                }
             }
-            for (; z < nsplit; ++z) s0 += src[(size_t)z * C];
-            d_bias[i] = (s0 + s1) + (s2 + s3);
+            red[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            __syncthreads();
+            if (wave == 0 && i < HC)
+                d_bias[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            __syncthreads();
         }
 }
 
@@ -1068,6 +1211,49 @@ static int dw_splits(int N, int H, int C, int F) {
     return want < 1 ? 1 : want;
 }
 
+
+// d_W by the register-streaming kernel when the head's result fits the accumulators
+struct DwPlan {
+    bool stream;
+    int nsplit, rows_per_split, ct, nt;
+};
+static DwPlan dw_plan(int N, int H, int C, int F) {
+    static const char *env = getenv("GATMI_DW_STREAM");   // A/B switch: 0 = tiled GEMM
+    DwPlan p{false, dw_splits(N, H, C, F), 0, (C + 31) / 32, (F + 31) / 32};
+    if (env && env[0] == '0') return p;
+    if (p.ct > 2 || p.nt > 4 || p.ct * p.nt > 8 || N < 4096) return p;
+    if (p.nt == 3) p.nt = 4;
+    long long waves = (long long)device_cus() * 8;         // two blocks of four waves per CU
+    int ns = (int)(waves / H);
+    const int maxs = N / 256;                              // >= 128 row pairs per wave
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    int rps = (N + ns - 1) / ns;
+    rps += rps & 1;                                        // even: pairs never straddle splits
+    ns = (N + rps - 1) / rps;
+    p.stream = true;
+    p.nsplit = ns;
+    p.rows_per_split = rps;
+    return p;
+}
+
+template <int CT, int NT>
+static void dw_stream_launch(const DwPlan &p, const float *g, const float *z, int N, int H, int C, int F,
+                             int Fp, float *slab, float *gsum, hipStream_t st) {
+    const int blocks = (H * p.nsplit + 3) / 4;
+    hipLaunchKernelGGL((inagg_dw_stream_kernel<CT, NT>), dim3(blocks), dim3(256), 0, st, g, H * C, z,
+                       H * Fp, N, H, C, F, Fp, p.nsplit, p.rows_per_split, slab, gsum);
+}
+static void dw_stream(const DwPlan &p, const float *g, const float *z, int N, int H, int C, int F, int Fp,
+                      float *slab, float *gsum, hipStream_t st) {
+    if (p.ct == 1 && p.nt == 1) dw_stream_launch<1, 1>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    else if (p.ct == 1 && p.nt == 2) dw_stream_launch<1, 2>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    else if (p.ct == 1) dw_stream_launch<1, 4>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    else if (p.nt == 1) dw_stream_launch<2, 1>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    else if (p.nt == 2) dw_stream_launch<2, 2>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    else dw_stream_launch<2, 4>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+}
+
 }  // namespace gatmi
 
 using namespace gatmi;
@@ -1222,7 +1408,7 @@ InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &ge
     w.waves = in_grid(geo, g->plan.n_items) * 4;
     w.part_y = cv.take<float>((size_t)w.waves * 2 * geo.HF);
     w.dwsd = cv.take<float>((size_t)2 * geo.HF);
-    w.nsplit = dw_splits(g->num_dst, s->heads, s->channels, s->in_features);
+    w.nsplit = dw_plan(g->num_dst, s->heads, s->channels, s->in_features).nsplit;
     w.slab = cv.take<float>((size_t)w.nsplit * s->heads * s->channels * s->in_features);
     w.gsum = cv.take<float>((size_t)w.nsplit * s->heads * s->channels);
     w.bytes = cv.off + 256;
@@ -1301,10 +1487,16 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
             d.bias = nullptr; d.sBias = 0;
             d.fix = AFix{nullptr, nullptr, 1, 1};
             d.asum = d_bias ? w.gsum : nullptr;   // [h][split][C]: d_bias rides on the staging of g
-            if (int e = launch_gemm(d, st)) return e;
+            const DwPlan dp = dw_plan(N, H, C, F);
+            if (dp.stream) {
+                dw_stream(dp, grad_out, z, N, H, C, F, geo.Fp, w.slab, d_bias ? w.gsum : nullptr, st);
+                GATMI_HIP(hipGetLastError());
+            } else if (int e = launch_gemm(d, st)) {
+                return e;
+            }
         }
         const long long tot = (long long)H * C * F;
-        const int blocks = (int)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+        const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
         hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab,
                            N > 0 ? w.nsplit : 0, H, C, F, geo.Fp, a->weight, a->att_src, a->att_dst,
                            w.dwsd, w.gsum, d_weight, d_att_src, d_att_dst, d_bias);

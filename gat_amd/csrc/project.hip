@@ -645,7 +645,7 @@ static void kres_launch(const GemmDesc &d, int nf4, hipStream_t st) {
                        d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, gb);
 }
 
-static int device_cus() {
+int device_cus() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
