@@ -1,7 +1,7 @@
 """Graph container and construction on the host, mirroring what the reference feeds its
 model: Data(x, edge_index, y) from /root/reference/gat/converter.py:18-24 with the kNN
-graph of :7-15 (k=5, include_self=True, scikit-learn on the CPU -- one-off, out of the hot
-path)."""
+graph of :7-15 (k=5, include_self=True): on the GPU by gat_amd/csrc/knn.hip (SURVEY.md 8f
+rank 2), or by the reference's own scikit-learn call on the host."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -31,9 +31,50 @@ class Data:
         return Data(mv(self.x), mv(self.edge_index), mv(self.y))
 
 
-def create_knn_graph(X, k: int = 5) -> torch.Tensor:
+def _values(X) -> np.ndarray:
+    return X.values if hasattr(X, "values") else np.asarray(X)
+
+
+def knn_graph_hip(X, k: int = 5, device=None) -> torch.Tensor:
+    """create_knn_graph on the GPU (gat_amd/csrc/knn.hip): exact fp64 brute force, same
+    edge_index layout as the scikit-learn call of /root/reference/gat/converter.py:8-15.
+    Returns an int64 [2, k*N] tensor on `device`."""
+    from . import _lib
+    if not torch.cuda.is_available():
+        raise RuntimeError("knn_graph_hip needs a GPU")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if isinstance(X, torch.Tensor):
+        x = X.to(device=dev, dtype=torch.float64).contiguous()
+    else:
+        x = torch.as_tensor(np.ascontiguousarray(_values(X), dtype=np.float64)).to(dev)
+    if x.dim() != 2:
+        raise ValueError(f"X must be [N, F], got {tuple(x.shape)}")
+    n, f = x.shape
+    if k > n:   # the message scikit-learn gives
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {n}")
+    lib = _lib.lib()
+    with torch.cuda.device(dev):
+        ei = torch.empty(2, k * n, dtype=torch.int64, device=dev)
+        ws = torch.empty(int(lib.gatmi_knn_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gatmi_knn_graph(x.data_ptr(), n, f, k, ei.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream(dev).cuda_stream), "gatmi_knn_graph")
+    return ei
+
+
+def create_knn_graph(X, k: int = 5, backend: str = "auto") -> torch.Tensor:
+    """/root/reference/gat/converter.py:7-15; returns a CPU int64 [2, k*N] tensor like the
+    reference.  backend "hip": computed on the GPU (knn_graph_hip keeps the result there);
+    "sklearn": the reference's own scikit-learn call on the host; "auto": "hip" when a GPU is
+    present and the shape is covered (F <= 64, k <= 16), else "sklearn"."""
+    values = _values(X)
+    if backend == "auto":
+        backend = "hip" if (torch.cuda.is_available() and values.ndim == 2 and values.shape[1] <= 64
+                            and k <= 16) else "sklearn"
+    if backend == "hip":
+        return knn_graph_hip(values, k).cpu()
+    if backend != "sklearn":
+        raise ValueError(f"unknown backend {backend!r}")
     from sklearn.neighbors import kneighbors_graph
-    values = X.values if hasattr(X, "values") else np.asarray(X)
     adj = kneighbors_graph(values, n_neighbors=k, mode="connectivity", include_self=True,
                            n_jobs=-1).tocoo()
     pairs = np.vstack([adj.row.astype(np.int64), adj.col.astype(np.int64)])

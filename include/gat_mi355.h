@@ -291,6 +291,16 @@ int gatmi_tail_bwd(int64_t rows, int32_t classes, const float *logp, const int64
                    const float *loss_stats, const float *grad_loss, const float *grad_logp,
                    float *grad_logits, void *stream);
 
+/* ---- kNN graph construction -----------------------------------------------------------------
+ * Replaces  create_knn_graph(X, k)  (/root/reference/gat/converter.py:7-15): scikit-learn's
+ * kneighbors_graph(X, k, mode="connectivity", include_self=True) -> COO -> edge_index.
+ * x: float64 [n, f] row-major (X.values), f <= 64, k <= 16, k <= n.  edge_index: int64 [2, k*n],
+ * row 0 = query i (k times, ascending), row 1 = its k nearest by ascending distance, itself
+ * included; exact fp64 brute force, equal distances resolved towards the lower index. */
+size_t gatmi_knn_workspace_bytes(int64_t n);
+int gatmi_knn_graph(const double *x, int64_t n, int32_t f, int32_t k, int64_t *edge_index,
+                    void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
