@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kres_kernel(const float *__restri
 // floats, at most 128) for the lifetime of the block, the contraction is unrolled over KC
 // steps, and all 160 KB of LDS are tile buffers: NBUF = 3-4 per wave, two or three in flight.
 // ---------------------------------------------------------------------------------
-template <int NT, int KC, bool SWZ>
+template <int NT, int KC, bool SWZ, bool TAIL>
 __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restrict__ A, int lda,
                                                            const float *__restrict__ B, int ldb,
                                                            int b_kmajor, float *__restrict__ C,
@@ -481,6 +481,30 @@ __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restri
     for (int nt = 0; nt < NT; ++nt) {
         const int cn = nt * 32 + l;
         bv[nt] = (bias && cn < Nn) ? bias[cn] : 0.f;
+    }
+    // TAIL: up to four more columns (NT*32 ...) go through v_mfma_f32_4x4x1_16B_f32 -- 16
+    // independent 4x4 blocks, lane 4b + i supplies the A of row i of block b, lane 4b + j the B
+    // of column j.  Blocks 0-7 are the tile's 32 rows on the k values of half 0, blocks 8-15 the
+    // same rows on those of half 1 -- exactly what a4[i] already holds; the halves are added in
+    // the epilogue.  8 cycles per step instead of the 64 of a fourth 32-wide tile.
+    float btail[TAIL ? KC : 1][4], bvt = 0.f;
+    if constexpr (TAIL) {
+        const int n = NT * 32 + (lane & 3);
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = 8 * j + 4 * half + i;
+                float v = 0.f;
+                if (kk < K && n < Nn) v = b_kmajor ? B[(size_t)kk * ldb + n] : B[(size_t)n * ldb + kk];
+                btail[j][i] = v;
+            }
+        bvt = (bias && n < Nn) ? bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(btail[j][i]));
+        asm volatile("" : "+v"(bvt));
     }
 #pragma unroll
     for (int j = 0; j < KC; ++j)
@@ -541,6 +565,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restri
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        f32x4 acct = {0.f, 0.f, 0.f, 0.f};
         auto a_read = [&](int j) {
             const int c = 2 * j + half;
             const int cc = c < nf4 ? c : 0;       // a pad chunk meets zero operands of B
@@ -560,6 +585,11 @@ __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restri
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], breg[j][i][nt], acc[nt], 0, 0, 0);
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acct = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[i], btail[j][i], acct, 0, 0, 0);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an));
             a4 = an;
         }
@@ -592,6 +622,16 @@ __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restri
                         if (row0 + 4 * half + dr < M) cp[(size_t)dr * ldc] = acc[nt][r] + bv[nt];
                     }
                 }
+            }
+        }
+        if constexpr (TAIL) {
+            // lane 4b + j holds rows 4b .. 4b+3 (register index) of column NT*32 + j
+            const int cn = NT * 32 + (lane & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float tot = acct[i] + __shfl_xor(acct[i], 32, 64);
+                const long long row = row0 + 4 * (l >> 2) + i;
+                if (half == 0 && cn < gb.n_store && row < M) C[(size_t)row * ldc + cn] = tot + bvt;
             }
         }
         if (t + (long long)nbuf * tstride < ntiles) issue(t + (long long)nbuf * tstride, buf);
@@ -656,7 +696,7 @@ int device_cus() {
     return cus;
 }
 
-template <int NT, int KC, bool SWZ>
+template <int NT, int KC, bool SWZ, bool TAIL = false>
 static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     const size_t tileb = (size_t)32 * nf4 * 16;
     int nbuf = (int)((160 * 1024) / (4 * tileb));
@@ -664,7 +704,7 @@ static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     const size_t lds = (size_t)4 * nbuf * tileb;
     static size_t dyn_cap = 0;   // dynamic LDS beyond 64 KiB has to be granted per kernel
     if (lds > dyn_cap) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kreg_kernel<NT, KC, SWZ>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kreg_kernel<NT, KC, SWZ, TAIL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             dyn_cap = lds;
     }
@@ -673,7 +713,7 @@ static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     if (bx > need) bx = need;
     if (bx < 1) bx = 1;
     GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, 1, d.n_store, nullptr};
-    hipLaunchKernelGGL((gemm_kreg_kernel<NT, KC, SWZ>), dim3((unsigned)bx, d.nbatch), dim3(256), lds, st,
+    hipLaunchKernelGGL((gemm_kreg_kernel<NT, KC, SWZ, TAIL>), dim3((unsigned)bx, d.nbatch), dim3(256), lds, st,
                        d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, nbuf, gb);
 }
 
@@ -694,6 +734,18 @@ static bool kreg_dispatch(const GemmDesc &d, int nf4, hipStream_t st) {
     return false;
 }
 
+static bool kreg_tail3(const GemmDesc &d, int nf4, hipStream_t st) {
+    static const char *env = getenv("GATMI_KREG");
+    static const char *envt = getenv("GATMI_KREG_TAIL");
+    if ((env && env[0] == '0') || (envt && envt[0] == '0')) return false;
+    const int kc = (nf4 + 1) / 2;
+    if ((size_t)4 * 3 * 32 * nf4 * 16 > 160 * 1024) return false;
+    if (nf4 == 16) { kreg_launch<3, 8, true, true>(d, nf4, st); return true; }
+    if (kc <= 4) { kreg_launch<3, 4, false, true>(d, nf4, st); return true; }
+    if (kc <= 8) { kreg_launch<3, 8, false, true>(d, nf4, st); return true; }
+    return false;
+}
+
 int launch_kres(const GemmDesc &d0, hipStream_t st) {
     GemmDesc d = d0;
     if (d.n_store < d.Nn) d.n_store = d.Nn;
@@ -702,7 +754,9 @@ int launch_kres(const GemmDesc &d0, hipStream_t st) {
     GATMI_REQUIRE(kres_covers(d), "K-resident GEMM does not cover this product");
     const int nf4 = (d.a_kpad > d.K ? d.a_kpad : d.K) / 4;
     const bool swz = nf4 == 16;
-    if (d.n_store <= 32) {
+    if (d.n_store > 96 && d.n_store <= 100 && kreg_tail3(d, nf4, st)) {
+        // three 32-wide tiles + a 4-column tail (F = 100: the products-shaped layer)
+    } else if (d.n_store <= 32) {
         if (!kreg_dispatch<1>(d, nf4, st)) swz ? kres_launch<1, true>(d, nf4, st) : kres_launch<1, false>(d, nf4, st);
     } else if (d.n_store <= 64) {
         if (!kreg_dispatch<2>(d, nf4, st)) swz ? kres_launch<2, true>(d, nf4, st) : kres_launch<2, false>(d, nf4, st);

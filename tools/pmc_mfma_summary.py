@@ -5,12 +5,12 @@ dst = sys.argv[1] if len(sys.argv) > 1 else "profiles/r1/pmc_mfma.txt"
 out = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (one pass per variant),",
        "# bench.py --steps 2 --warmup 1, products-shaped.  GRBM_GUI_ACTIVE is summed over the 8 XCDs;",
        "# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)  (v_mfma_f32_32x32x2_f32 = 64 busy cycles)"]
-for v, label in (("auto", "input-side aggregation path (gemm_kres<2,false>: out = Z W^T | gemm_kres<4,true>: q = g W | gemm_f32<true,true,64,128>: dW = g^T Z)"),
+for v, label in (("auto", "input-side aggregation path (gemm_kreg<2,13,false>: out = Z W^T | gemm_kreg<4,8,true>: q = g W | inagg_dw_stream<2,4>: dW = g^T Z)"),
                  ("off", "projected-row path (gemm_f32<false,false,..>: h = x W^T | gemm_f32<true,true,..>: dW = d_h^T x)")):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(f"gpurun_out/pmc_mfma_{v}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.search(r"gatmi::(gemm_\w+<[^>]*>)", row["Kernel_Name"])
+            m = re.search(r"gatmi::((?:gemm_\w+|inagg_dw_stream_kernel)<[^>]*>)", row["Kernel_Name"])
             if m:
                 acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
     out.append(f"== {label}")
