@@ -811,9 +811,10 @@ __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const f
 // on the A operands.
 // ---------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
 constexpr int kDwBank = 6;
 
-template <int CT, int NT>
+template <int CT, int NT, bool TAIL>
 __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
     const float *__restrict__ g, int ldg, const float *__restrict__ z, int ldz, int N, int H, int C,
     int F, int Fp, int nsplit, int rows_per_split, float *__restrict__ slab, float *__restrict__ gsum) {
@@ -831,6 +832,13 @@ __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
     for (int ct = 0; ct < CT; ++ct) go[ct] = (unsigned)(half * ldg + h * C + min(l + 32 * ct, C - 1)) * 4u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) zo[nt] = (unsigned)(half * ldz + h * Fp + min(l + 32 * nt, Fp - 1)) * 4u;
+    // TAIL (CT == 2): columns NT*32 .. NT*32+3 through v_mfma_f32_4x4x1_16B_f32, one row per
+    // instruction: lane c supplies g[n][c] (the two halves of the 32x32 A operands, swapped into
+    // place), lane 4b + j supplies Z[n][NT*32 + j]; block b holds rows 4b .. 4b+3 of the result.
+    unsigned zt[2];
+    zt[0] = (unsigned)(h * Fp + min(NT * 32 + (lane & 3), Fp - 1)) * 4u;
+    zt[1] = zt[0] + (unsigned)ldz * 4u;
+    f32x4t acct = {0.f, 0.f, 0.f, 0.f};
     const char *gb0 = reinterpret_cast<const char *>(g + (size_t)n_beg * ldg);
     const char *zb0 = reinterpret_cast<const char *>(z + (size_t)n_beg * ldz);
     f32x16 acc[CT][NT];
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
     // the edge kernels use; hipcc counts vmcnt across the loop for it, which it does not for a
     // per-step ring: it drained every load at the top of each trip).
     struct Bank {
-        float ga[kDwBank][CT], zb[kDwBank][NT];
+        float ga[kDwBank][CT], zb[kDwBank][NT], zt[kDwBank][TAIL ? 2 : 1];
     };
     auto load = [&](Bank &bk, int p0) {
 #pragma unroll
@@ -862,6 +870,10 @@ __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
             for (int ct = 0; ct < CT; ++ct) bk.ga[d][ct] = *reinterpret_cast<const float *>(gr + go[ct]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bk.zb[d][nt] = *reinterpret_cast<const float *>(zr + zo[nt]);
+            if constexpr (TAIL) {
+                bk.zt[d][0] = *reinterpret_cast<const float *>(zr + zt[0]);
+                bk.zt[d][1] = *reinterpret_cast<const float *>(zr + zt[1]);
+            }
         }
     };
     auto mult = [&](const Bank &bk, int p0) {
@@ -891,6 +903,11 @@ __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
     }
     if (nrows & 1) {                                          // the odd last row: k = 1 is zero
         const size_t row = (size_t)(n_end - 1);
+        if constexpr (TAIL) {
+            const float gv = g[row * ldg + h * C + min(lane, C - 1)] * (lane < C ? 1.f : 0.f);
+            const float zv = z[row * ldz + h * Fp + min(NT * 32 + (lane & 3), Fp - 1)];
+            acct = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, zv, acct, 0, 0, 0);
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const float v = g[row * ldg + h * C + min(l + 32 * ct, C - 1)];
@@ -915,6 +932,14 @@ __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
                 if (c < C && f < F) dst[(size_t)c * F + f] = acc[ct][nt][r];
             }
         }
+    if constexpr (TAIL) {
+        const int f = NT * 32 + (lane & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * (lane >> 2) + i;
+            if (c < C && f < F) dst[(size_t)c * F + f] = acct[i];
+        }
+    }
     if (gsum) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -1216,13 +1241,20 @@ static int dw_splits(int N, int H, int C, int F) {
 struct DwPlan {
     bool stream;
     int nsplit, rows_per_split, ct, nt;
+    bool tail;
 };
 static DwPlan dw_plan(int N, int H, int C, int F) {
     static const char *env = getenv("GATMI_DW_STREAM");   // A/B switch: 0 = tiled GEMM
-    DwPlan p{false, dw_splits(N, H, C, F), 0, (C + 31) / 32, (F + 31) / 32};
+    DwPlan p{false, dw_splits(N, H, C, F), 0, (C + 31) / 32, (F + 31) / 32, false};
     if (env && env[0] == '0') return p;
     if (p.ct > 2 || p.nt > 4 || p.ct * p.nt > 8 || N < 4096) return p;
-    if (p.nt == 3) p.nt = 4;
+    static const char *envt = getenv("GATMI_DW_TAIL");   // A/B switch: 0 = a fourth 32-wide tile
+    if (p.ct == 2 && F > 96 && F <= 100 && !(envt && envt[0] == '0')) {
+        p.nt = 3;
+        p.tail = true;
+    } else if (p.nt == 3) {
+        p.nt = 4;
+    }
     long long waves = (long long)device_cus() * 8;         // two blocks of four waves per CU
     int ns = (int)(waves / H);
     const int maxs = N / 256;                              // >= 128 row pairs per wave
@@ -1237,16 +1269,17 @@ static DwPlan dw_plan(int N, int H, int C, int F) {
     return p;
 }
 
-template <int CT, int NT>
+template <int CT, int NT, bool TAIL = false>
 static void dw_stream_launch(const DwPlan &p, const float *g, const float *z, int N, int H, int C, int F,
                              int Fp, float *slab, float *gsum, hipStream_t st) {
     const int blocks = (H * p.nsplit + 3) / 4;
-    hipLaunchKernelGGL((inagg_dw_stream_kernel<CT, NT>), dim3(blocks), dim3(256), 0, st, g, H * C, z,
+    hipLaunchKernelGGL((inagg_dw_stream_kernel<CT, NT, TAIL>), dim3(blocks), dim3(256), 0, st, g, H * C, z,
                        H * Fp, N, H, C, F, Fp, p.nsplit, p.rows_per_split, slab, gsum);
 }
 static void dw_stream(const DwPlan &p, const float *g, const float *z, int N, int H, int C, int F, int Fp,
                       float *slab, float *gsum, hipStream_t st) {
-    if (p.ct == 1 && p.nt == 1) dw_stream_launch<1, 1>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    if (p.tail) dw_stream_launch<2, 3, true>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
+    else if (p.ct == 1 && p.nt == 1) dw_stream_launch<1, 1>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
     else if (p.ct == 1 && p.nt == 2) dw_stream_launch<1, 2>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
     else if (p.ct == 1) dw_stream_launch<1, 4>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
     else if (p.nt == 1) dw_stream_launch<2, 1>(p, g, z, N, H, C, F, Fp, slab, gsum, st);
