@@ -880,13 +880,21 @@ __global__ __launch_bounds__(256, 2) void inagg_dw_stream_kernel(
 #pragma unroll
         for (int d = 0; d < kDwBank; ++d) {
             if (p0 + d < np) {                                // wave-uniform
+                float a[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const float a = bk.ga[d][ct] * cmask[ct];
-                    gs[ct] += a;
+                    a[ct] = bk.ga[d][ct] * cmask[ct];
+                    gs[ct] += a[ct];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bk.zb[d][nt], acc[ct][nt], 0, 0, 0);
+                        acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct], bk.zb[d][nt], acc[ct][nt], 0, 0, 0);
+                }
+                if constexpr (TAIL) {
+                    const float o0 = __shfl_xor(a[0], 32, 64), o1 = __shfl_xor(a[CT - 1], 32, 64);
+                    const float r0 = half ? o1 : a[0];            // g[n0][lane]
+                    const float r1 = half ? a[CT - 1] : o0;       // g[n0 + 1][lane]
+                    acct = __builtin_amdgcn_mfma_f32_4x4x1f32(r0, bk.zt[d][0], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_4x4x1f32(r1, bk.zt[d][1], acct, 0, 0, 0);
                 }
             }
         }

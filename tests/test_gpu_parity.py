@@ -236,6 +236,26 @@ def test_streaming_forward_medium_graph(cuda):
     close(out, out2, "stream vs registers")
 
 
+@pytest.mark.parametrize("n,f,h,c", [(4099, 100, 4, 64), (4613, 128, 4, 64), (5001, 98, 4, 40),
+                                     (4101, 25, 8, 30), (4097, 97, 2, 64), (6007, 60, 3, 33)])
+def test_input_aggregation_ragged_gemm_tiles(cuda, n, f, h, c):
+    """Node counts past the 4096 rows where the register-resident GEMMs take over, none of them
+    a multiple of 32: partial last row tile of out = Z W^T and q = g W, odd last row of the d_W
+    row pairs, the 4-column MFMA tail (F = 97..100), channel counts that leave the second
+    32-wide tile ragged -- against the oracle, both forward kernels."""
+    from gat_amd import synth
+    ei = synth.powerlaw_graph(n, 9 * n, 700, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 1)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for stream in (True, False):
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True, stream=stream)
+        close(out, ref_out, "out")
+        for k in g:
+            close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 def test_input_aggregation_properties_at_scale(cuda):
     """products-sized table (beyond the Infinity Cache: the streaming kernel is what auto picks):
     identical rows in -> identical rows + bias out (the softmax weights of every destination sum
