@@ -730,7 +730,8 @@ __global__ void inagg_wsd_kernel(const float *w, const float *att_src, const flo
 // Packed source table: xs[n] = x[n] (Fp floats, zero padded) | a_src[n, 0..H) | zero pad, and
 // a_dst[n, h] = <x[n], wd_h>.  A row is owned by gl = next_pow2(Fp/4) (<= 64) lanes, each holding
 // up to KS float4 of it; per-head dots are butterflies over those lanes.
-template <int KS>
+// GL = lanes per row when known at compile time (DPP butterflies), 0 = run-time width
+template <int KS, int GL>
 __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const float *wsd, long long n,
                                                          int F, int Fp, int Fs, int H, int glog,
                                                          float *xs, float *a_dst) {
@@ -782,11 +783,7 @@ __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const f
                         pk_dot4(dd, xv[u][k], ldv4(s_wsd + HF + h * Fp + sub * 4));
                     }
                 }
-                float a = ds.x + ds.y, d = dd.x + dd.y;
-                for (int o = 1; o < gl; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    d += __shfl_xor(d, o, 64);
-                }
+                const float a = head_sum<GL>(ds.x + ds.y, gl), d = head_sum<GL>(dd.x + dd.y, gl);
                 if (on && sl == 0) {
                     xs[row * Fs + Fp + h] = a;
                     a_dst[row * H + h] = d;
@@ -1352,18 +1349,16 @@ extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const floa
     if (blocks > 2048) blocks = 2048;
     const int glog = ilog2(gl);
     const long long n = s->num_nodes;
-    if (ks == 1)
-        hipLaunchKernelGGL(inagg_pack_kernel<1>, dim3((unsigned)blocks), dim3(256),
-                           (size_t)2 * geo.HF * sizeof(float), st, x, wsd, n, F,
-                           geo.Fp, geo.Fs, H, glog, xs, a_dst);
-    else if (ks == 2)
-        hipLaunchKernelGGL(inagg_pack_kernel<2>, dim3((unsigned)blocks), dim3(256),
-                           (size_t)2 * geo.HF * sizeof(float), st, x, wsd, n, F,
-                           geo.Fp, geo.Fs, H, glog, xs, a_dst);
-    else
-        hipLaunchKernelGGL(inagg_pack_kernel<4>, dim3((unsigned)blocks), dim3(256),
-                           (size_t)2 * geo.HF * sizeof(float), st, x, wsd, n, F,
-                           geo.Fp, geo.Fs, H, glog, xs, a_dst);
+    const size_t lds = (size_t)2 * geo.HF * sizeof(float);
+#define GATMI_PACK(KS, GL)                                                                       \
+    hipLaunchKernelGGL((inagg_pack_kernel<KS, GL>), dim3((unsigned)blocks), dim3(256), lds, st, x, wsd, n, \
+                       F, geo.Fp, geo.Fs, H, glog, xs, a_dst)
+    if (ks == 1 && gl == 32) GATMI_PACK(1, 32);         // F = 65 .. 128: the layers BASELINE.json names
+    else if (ks == 1 && gl == 8) GATMI_PACK(1, 8);      // run.py's 25 features
+    else if (ks == 1) GATMI_PACK(1, 0);
+    else if (ks == 2) GATMI_PACK(2, 64);
+    else GATMI_PACK(4, 64);
+#undef GATMI_PACK
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
