@@ -3,8 +3,9 @@
 The reference runs `run_experiment(config)` for one configuration after another in one
 process (/root/reference/grid_search.py:70-118, random_search.py:113-146 and three more
 verbatim clones).  Trials share nothing, so under `torch.distributed.run` rank r simply
-takes configurations r, r + P, r + 2P ... on its own GPU: no collective touches the data
-path; the per-trial results are gathered once at the end over gloo.  Without a launcher
+takes configurations r, r + P, r + 2P ... on its own GPU (or, schedule="dynamic", whatever a
+shared counter hands it next): no collective touches the data path; the per-trial results are
+gathered once at the end over gloo.  Without a launcher
 (WORLD_SIZE unset) everything runs in this process, in the reference's order.
 """
 from __future__ import annotations
@@ -110,17 +111,37 @@ def world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def run_trials(configs: Sequence[Config], experiment: Callable[[Config], ConfigResults] = run_experiment
-               ) -> List[ConfigResults]:
-    """All configurations, sharded round-robin over the ranks; every rank returns the full
-    list in configuration order."""
+_CALLS = 0
+
+
+def run_trials(configs: Sequence[Config], experiment: Callable[[Config], ConfigResults] = run_experiment,
+               schedule: str = "static") -> List[ConfigResults]:
+    """All configurations over the ranks; every rank returns the full list in configuration
+    order.  schedule "static": rank r takes r, r + P, ... (no communication until the end);
+    "dynamic": a shared counter in the process group's store hands out the next configuration
+    to whichever GPU is free -- trials differ in epochs, width and early stopping, so their
+    run times do.  Either way no collective touches the data path."""
+    global _CALLS
+    if schedule not in ("static", "dynamic"):
+        raise ValueError(f"unknown schedule {schedule!r}")
     rank, size = world()
-    mine = [(i, experiment(c)) for i, c in enumerate(configs) if i % size == rank]
     if size == 1:
-        return [r for _, r in mine]
+        return [experiment(c) for c in configs]
     import torch.distributed as dist
     if not dist.is_initialized():
         dist.init_process_group("gloo")       # results only: a few floats per trial
+    _CALLS += 1
+    if schedule == "static":
+        mine = [(i, experiment(c)) for i, c in enumerate(configs) if i % size == rank]
+    else:
+        store = dist.distributed_c10d._get_default_store()
+        key = f"gat_amd/trials/{_CALLS}/next"
+        mine = []
+        while True:
+            i = int(store.add(key, 1)) - 1    # atomic fetch-and-add on rank 0's store
+            if i >= len(configs):
+                break
+            mine.append((i, experiment(configs[i])))
     slim = [(i, _portable(r)) for i, r in mine]
     gathered = [None] * size
     dist.all_gather_object(gathered, slim)

@@ -36,9 +36,11 @@ def main():
     ap.add_argument("--samples", type=int, default=NUM_SAMPLES)
     ap.add_argument("--runs", type=int, default=NUM_RUNS)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--schedule", default="dynamic", choices=["static", "dynamic"],
+                    help="how trials are handed to the GPUs (gat_amd/trials.py)")
     args = ap.parse_args()
     configs = sample_configs(args.samples, args.seed)
-    results = run_trials(configs, lambda c: run_experiment(c, args.runs))
+    results = run_trials(configs, lambda c: run_experiment(c, args.runs), schedule=args.schedule)
     if world()[0] == 0:
         best, score = best_of(results)
         print(f"Best config: {best} with composite score: {score}")

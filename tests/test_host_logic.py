@@ -52,6 +52,43 @@ def test_shim_import_paths():
     assert c2g is convert_to_graph and M is Metrics and GAT.__name__ == "GAT"
 
 
+def _dynamic_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from gat_amd import trials
+    configs = [trials.Config(torch.optim.AdamW, 0.01 * i, 5e-4, 3, 2, 16, 0.4) for i in range(7)]
+    ran = []
+
+    def fake(cfg):
+        ran.append(cfg.lr)
+        time.sleep(0.6 if cfg.lr == 0.0 else 0.05)      # the first trial is a long one
+        return trials.ConfigResults(cfg, [Metrics()], cfg.lr, 1.0, 1.0, cfg.lr, cfg.lr, cfg.lr, cfg.lr)
+
+    for _ in range(2):                                   # two searches in one process group
+        del ran[:]
+        res = trials.run_trials(configs, fake, schedule="dynamic")
+    q.put((rank, list(ran), [r.composite_score for r in res], [r.config.lr for r in res]))
+    dist.destroy_process_group()
+
+
+def test_trials_dynamic_queue_hands_out_each_configuration_once():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dynamic_worker, args=(r, 2, 29623, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    want = [0.01 * i for i in range(7)]
+    assert sorted(got[0][1] + got[1][1]) == want           # every configuration ran exactly once
+    long_owner = got[0] if 0.0 in got[0][1] else got[1]
+    assert len(long_owner[1]) < 4                           # the rank stuck on the long trial took fewer
+    for _, _, scores, lrs in got:
+        assert scores == want and lrs == want
+
+
 def _trial_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world))
