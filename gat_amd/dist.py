@@ -345,6 +345,91 @@ class PartitionedGATConv(nn.Module):
         return self.exchange
 
 
+# ------------------------------------------------------------------ the whole network, partitioned
+class _SumRanks(torch.autograd.Function):
+    """y = sum over ranks of x (every rank gets y).  Each rank back-propagates its OWN share of
+    the loss, so the gradient arriving at y on a rank is that rank's partial; the gradient of
+    x is their sum: the backward is the same all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        y = x.contiguous().clone()
+        dist.all_reduce(y, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+def sync_elu_bn_dropout(x_local: Tensor, bn: nn.BatchNorm1d, p: float, training: bool,
+                        num_nodes: int, group=None) -> Tensor:
+    """dropout(bn(elu(x))) (/root/reference/gat/model.py:40-42) on a row partition: BatchNorm's
+    batch statistics are those of ALL N rows (full-model caveat) -- two tiny
+    all-reduces forward ([D] sums: mean, then centred squares, so no E[x^2] - mean^2
+    cancellation) and their adjoints backward.  Running statistics update as nn.BatchNorm1d
+    does (unbiased variance, momentum), identically on every rank.  Eval mode is local."""
+    e = torch.nn.functional.elu(x_local)
+    if training:
+        mean = _SumRanks.apply(e.sum(0), group) / num_nodes
+        cen = e - mean
+        var = _SumRanks.apply((cen * cen).sum(0), group) / num_nodes
+        with torch.no_grad():
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(m * mean)
+            bn.running_var.mul_(1 - m).add_(m * var * (num_nodes / max(num_nodes - 1, 1)))
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        y = cen * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+    else:
+        y = (e - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias
+    return torch.nn.functional.dropout(y, p, training)
+
+
+class PartitionedGAT(nn.Module):
+    """The reference's network (/root/reference/gat/model.py:26-31, 37-47) on one large graph
+    split over the ranks by destination: rank r holds rows [lo, hi) of x and y.  The three
+    layers are PartitionedGATConv (their parameter gradients come back all-reduced), the two
+    BatchNorms use global batch statistics, the loss is the mean over all N nodes.  Every rank
+    back-propagates its own rows' share of that mean; call `sync_grads()` before the optimizer
+    step (BatchNorm's weight and bias gradients are partial sums until then)."""
+
+    def __init__(self, num_features, num_classes, hidden_dim=16, dropout=0.7, backend=None, group=None):
+        super().__init__()
+        kw = dict(dropout=dropout, backend=backend, group=group)
+        self.conv1 = PartitionedGATConv(num_features, hidden_dim, heads=8, **kw)
+        self.bn1 = nn.BatchNorm1d(hidden_dim * 8)
+        self.conv2 = PartitionedGATConv(hidden_dim * 8, hidden_dim, heads=8, **kw)
+        self.bn2 = nn.BatchNorm1d(hidden_dim * 8)
+        self.conv3 = PartitionedGATConv(hidden_dim * 8, num_classes, heads=1, **kw)
+        self.p, self.group = dropout, group
+
+    def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
+        drop = lambda t: torch.nn.functional.dropout(t, self.p, self.training)
+        x = self.conv1(drop(x_local), edge_index, num_nodes)
+        x = sync_elu_bn_dropout(x, self.bn1, self.p, self.training, num_nodes, self.group)
+        x = self.conv2(x, edge_index, num_nodes)
+        x = sync_elu_bn_dropout(x, self.bn2, self.p, self.training, num_nodes, self.group)
+        return torch.log_softmax(self.conv3(x, edge_index, num_nodes), dim=1)
+
+    def loss_share(self, logp_local: Tensor, y_local: Tensor, num_nodes: int) -> Tensor:
+        """This rank's share of F.nll_loss(out, y) over all N nodes (model.py:53): the shares of
+        all ranks add up to the reference's loss; back-propagate the share."""
+        return torch.nn.functional.nll_loss(logp_local, y_local, reduction="sum") / num_nodes
+
+    def global_loss(self, share: Tensor) -> Tensor:
+        total = share.detach().clone()
+        dist.all_reduce(total, group=self.group)
+        return total
+
+    def sync_grads(self) -> None:
+        all_reduce_many([p.grad for bn in (self.bn1, self.bn2) for p in (bn.weight, bn.bias)],
+                        group=self.group)
+
+
 # ------------------------------------------------------------------ bench.py --gpus N
 EXCHANGE_TEXT = {
     "h": "all-gather(h) fwd, reduce-scatter(d_h) + all-reduce(param grads) bwd",

@@ -177,3 +177,69 @@ def test_local_edges_keep_reference_order():
         assert torch.equal(loc[0], norm[0][sel])
         assert torch.equal(loc[1] + part.lo, norm[1][sel])
     assert sum(Partition(n, 3, r).n_local for r in range(3)) == n
+
+
+def _model_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gat_amd.dist import Partition, PartitionedGAT
+        torch.set_num_threads(1)
+        ei, n = cases.random_multigraph(n=61, e=400)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(n, 9, generator=g, dtype=torch.float64)
+        y = torch.randint(0, 3, (n,), generator=g)
+        torch.manual_seed(5)
+        ref = O.OracleGAT(9, 3, hidden_dim=4, dropout=0.0).double()
+        with torch.no_grad():       # biases that are not zero, BatchNorm parameters that are not 1 / 0
+            for p in ref.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn(p.shape, generator=g, dtype=torch.float64) * 0.3)
+        model = PartitionedGAT(9, 3, hidden_dim=4, dropout=0.0, backend=OracleBackend()).double()
+        model.load_state_dict(ref.state_dict())
+        part = Partition(n, world, rank)
+        for step in range(2):        # second step: running statistics carried over
+            ref.train(); ref.zero_grad()
+            ref_logp = ref(x, ei)
+            ref_loss = torch.nn.functional.nll_loss(ref_logp, y)
+            ref_loss.backward()
+            model.train(); model.zero_grad()
+            logp = model(x[part.lo:part.hi], ei, n)
+            share = model.loss_share(logp, y[part.lo:part.hi], n)
+            share.backward()
+            model.sync_grads()
+            tol = dict(rtol=1e-8, atol=1e-10)
+            torch.testing.assert_close(logp.detach(), ref_logp.detach()[part.lo:part.hi], **tol)
+            torch.testing.assert_close(model.global_loss(share), ref_loss.detach(), **tol)
+            rp = dict(ref.named_parameters())
+            for name, p in model.named_parameters():
+                torch.testing.assert_close(p.grad, rp[name].grad, **tol, msg=lambda m, name=name: f"{name}: {m}")
+            for name, b in model.named_buffers():
+                torch.testing.assert_close(b, dict(ref.named_buffers())[name], **tol,
+                                           msg=lambda m, name=name: f"{name}: {m}")
+        ref.eval(); model.eval()
+        with torch.no_grad():
+            torch.testing.assert_close(model(x[part.lo:part.hi], ei, n), ref(x, ei)[part.lo:part.hi], **tol)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29631), (3, 29632)])
+def test_partitioned_network_equals_single_process(world, port):
+    """The 3-layer network with BatchNorm statistics and the loss taken over all ranks' rows:
+    log-probabilities, loss, every parameter gradient and the running statistics of two training
+    steps, then eval mode, against the single-process oracle network."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
