@@ -109,6 +109,14 @@ __device__ __forceinline__ float exp_fast(float x) {
     return fmaf(e, r * 0.693147182464599609375f, e);
 }
 
+// exp(x) for x <= 0 as v_exp_f32(x * log2 e), no compensation: the product's rounding leaves a
+// relative error of |x| * 4e-8 (6e-7 at x = -15, where the weight itself is 3e-7 of the row's
+// largest).  Two instructions instead of seven; used where the exponential sits in the per-edge
+// loop of a VALU-bound kernel.
+__device__ __forceinline__ float exp_quick(float x) {
+    return __builtin_amdgcn_exp2f(fmaxf(x, -87.0f) * 1.44269502162933349609375f);
+}
+
 // Attention-dropout keep decision of (edge e in dst-CSR order, head): a counter-based
 // hash of (seed, e, head), identical in forward, backward and gatmi_dropout_mask.
 __device__ __forceinline__ bool keep_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t thr,

@@ -423,9 +423,9 @@ __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
                     const float z0 = u0 > 0.f ? u0 : A.neg_slope * u0;
                     const float z1 = two ? (u1 > 0.f ? u1 : A.neg_slope * u1) : -INFINITY;
                     const float mn = fmaxf(m, fmaxf(z0, z1));
-                    const float sc = exp_fast(m - mn);
-                    const float p0 = exp_fast(z0 - mn);
-                    const float p1 = two ? exp_fast(z1 - mn) : 0.f;
+                    const float sc = exp_quick(m - mn);
+                    const float p0 = exp_quick(z0 - mn);
+                    const float p1 = two ? exp_quick(z1 - mn) : 0.f;
                     ssum = fmaf(ssum, sc, p0 + p1);
                     // the second edge of the pair may sit in the next 64-edge mask window
                     unsigned sb0 = (unsigned)__builtin_amdgcn_readlane(kb, e - kbase);
