@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
                 float mn = m[t];
 #pragma unroll
                 for (int u = 0; u < U; ++u) mn = fmaxf(mn, z[u][t]);
-                const float sc = exp_fast(m[t] - mn);
+                const float sc = exp_quick(m[t] - mn);
                 ssum[t] *= sc;
                 scale4(acc[t], sc);
                 m[t] = mn;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
                 const unsigned sb = (unsigned)group_bcast<G>(kb, min(k0 + u, n - 1), gbase);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    const float p = live ? exp_fast(z[u][t] - m[t]) : 0.f;
+                    const float p = live ? exp_quick(z[u][t] - m[t]) : 0.f;
                     ssum[t] += p;
                     fma4(acc[t], (sb & hbit[t]) ? p * A.inv_keep : 0.f, v[u][t]);
                 }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
                     const float d2 = head_sum<LPH2_T>(dot4(v[u][t], hj[t]), lph2);
                     const float uu = asj[t] + q[u][t].x;
                     const float zz = uu > 0.f ? uu : A.neg_slope * uu;
-                    const float alpha = live ? exp_fast(zz - q[u][t].y) : 0.f;
+                    const float alpha = live ? exp_quick(zz - q[u][t].y) : 0.f;
                     const float at = (sb & hbit[t]) ? alpha * A.inv_keep : 0.f;
                     const float du = (at * d2 - alpha * q[u][t].z) * (uu > 0.f ? 1.0f : A.neg_slope);
                     fma4(acc[t], at, v[u][t]);

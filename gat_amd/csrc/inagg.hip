@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
                     z[u] = (k0 + u < n) ? zz : -INFINITY;
                     mn = fmaxf(mn, z[u]);
                 }
-                const float sc = exp_fast(m - mn);
+                const float sc = exp_quick(m - mn);
                 ssum *= sc;
 #pragma unroll
                 for (int t = 0; t < T; ++t) pk_scale4(acc[t], sc);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
                 for (int u = 0; u < U; ++u) {
                     const bool live = k0 + u < n;
                     const unsigned sb = (unsigned)group_bcast<G>(kb, min(k0 + u, n - 1), gbase);
-                    const float p = live ? exp_fast(z[u] - m) : 0.f;
+                    const float p = live ? exp_quick(z[u] - m) : 0.f;
                     ssum += p;
                     const float w = (sb & hbit) ? p * A.inv_keep : 0.f;
 #pragma unroll
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
                     const unsigned sb = (unsigned)group_bcast<G>(kb, min(k0 + u, n - 1), gbase);
                     const float uu = as[u] + adi;
                     const float zz = uu > 0.f ? uu : A.neg_slope * uu;
-                    const float alpha = live ? exp_fast(zz - lse_i) : 0.f;
+                    const float alpha = live ? exp_quick(zz - lse_i) : 0.f;
                     const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
                     const float du = (at * d2 - alpha * S) * (uu > 0.f ? 1.0f : A.neg_slope);
                     dad += du;
