@@ -113,8 +113,8 @@ __device__ __forceinline__ float exp_fast(float x) {
 // relative error of |x| * 4e-8 (6e-7 at x = -15, where the weight itself is 3e-7 of the row's
 // largest).  Two instructions instead of seven; used where the exponential sits in the per-edge
 // loop of a VALU-bound kernel.
-__device__ __forceinline__ float exp_quick(float x) {
-    return __builtin_amdgcn_exp2f(fmaxf(x, -87.0f) * 1.44269502162933349609375f);
+__device__ __forceinline__ float exp_quick(float x) {   // x = -inf gives 0 (no clamp needed)
+    return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f);
 }
 
 // Attention-dropout keep decision of (edge e in dst-CSR order, head): a counter-based
