@@ -472,9 +472,11 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
 
     for _ in range(args.warmup):
         step()
+    _lib.prof_read()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    _lib.prof_enable(True)          # per-kernel HIP events, as in the single-GPU run
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -482,8 +484,23 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    _lib.prof_enable(False)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    per = {}
+    for tag, ms in _lib.prof_read():
+        per.setdefault(tag, []).append(ms)
+    avg = {k: sum(v) / len(v) for k, v in per.items()}
+    # roofline of rank 0's dominant kernel on ITS share: local destination rows, local edges
+    kb = synth.kernel_bytes(part.n_local, layout.num_edges, h, h * c, f)
+    roofline = None
+    if any(k in avg for k in kb):
+        dom = max(kb, key=lambda k: avg.get(k, 0.0))
+        achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom],
+                    "scope": f"rank 0 of {world}: {part.n_local} destination rows, {layout.num_edges} edges"}
     if rank == 0:
         res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
                "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -496,6 +513,8 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                           "parallelism": f"destination partition x{world}, exchange={mode}: "
                                          + EXCHANGE_TEXT[mode] + f", {dist.get_backend()}",
                           "graph_layout_build_s": round(t_layout, 4)},
-               "roofline": None, "cpu_baseline": None}
+               "roofline": roofline,
+               "kernels": {k: {"avg_ms": round(v, 4)} for k, v in sorted(avg.items())},
+               "cpu_baseline": None}
         print(json.dumps(res))
     dist.destroy_process_group()

@@ -50,3 +50,23 @@ def workload_graph(name: str, seed: int = 0, device="cpu", scale: float = 1.0):
     if name.startswith("runpy"):
         return out_degree_k_graph(n, 5, seed, device), n, f, h, c
     return powerlaw_graph(n, e, int(dmax * max(scale, 0.05)) if dmax else 0, seed, device), n, f, h, c
+
+
+def kernel_bytes(n, e, h, d, f):
+    """Algorithmic bytes per launch of the two heavy edge kernels (fp32 values, int32
+    indices).  Forward is SURVEY.md 8d's B_fwd.  The backward gathers
+    features once instead of SURVEY 8d's twice: one pass over the transposed CSR reads, per
+    edge, the grad_out row (4D), the destination's 16H-byte record, col_t and pos_t, and
+    writes d_u (4H); per node it reads h, writes d_h and d_a_src."""
+    fp = (f + 3) // 4 * 4
+    fs = fp + (h + 3) // 4 * 4        # packed source row: x | a_src
+    return {
+        "attn_fwd": e * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
+        "attn_bwd_edge": e * (4 * d + 16 * h + 8 + 4 * h) + n * (8 * d + 4 * h),
+        # input-side aggregation (gat_amd/csrc/inagg.hip): an edge moves a packed source row
+        # x | a_src (4 Fs bytes) and its col index; a node reads rowptr and a_dst, writes Z [H, Fp]
+        # and lse (forward); reads its own packed row, q and Z [H, Fp], a_dst and lse (backward;
+        # nothing is written per edge or per node)
+        "inagg_fwd": e * (4 * fs + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h),
+        "inagg_bwd_edge": e * (4 * fs + 4) + n * (4 + 4 * fs + 8 * h * fp + 8 * h),
+    }
