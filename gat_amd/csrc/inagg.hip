@@ -609,6 +609,9 @@ __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
 // H2 <= 8 (table of 64 * H2 * 8 bytes per wave).
 // ---------------------------------------------------------------------------------
 constexpr int kBwd2MaxH2 = 8;
+#ifndef GATMI_BWD2_U2
+#define GATMI_BWD2_U2 2   // edges per batch (3: 128 VGPRs with spills in the loop, 9.9 ms)
+#endif
 #ifndef GATMI_BWD2_OCC
 #define GATMI_BWD2_OCC 4   // waves per SIMD the register allocation is held to (114 VGPRs; at 5
                          // it spills 20 registers into the edge loop: 11.5 instead of 8.9 ms)
@@ -616,7 +619,7 @@ constexpr int kBwd2MaxH2 = 8;
 
 template <int LH_T, int G, int T>
 __global__ __launch_bounds__(256, GATMI_BWD2_OCC) void inagg_bwd2_kernel(const InArgs A, int H2) {
-    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 2);
+    constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_BWD2_U2 : 2);
     __shared__ f2 cs_all[4][64 * kBwd2MaxH2];
     INAGG_PROLOGUE
     f2 *cs = cs_all[threadIdx.x >> 6] + gbase * H2;      // this group's table: [edge][H2]
