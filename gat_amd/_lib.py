@@ -103,6 +103,7 @@ SYMBOLS = {
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_tail_bwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gatmi_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "gatmi_knn_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gatmi_knn_graph": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
@@ -150,6 +151,11 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = lib().gatmi_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {code}): {msg}")
+
+
+def set_option(name: str, value: int) -> None:
+    """Kernel-selection switch (gatmi_set_option): value 0/1, -1 hands it back to the environment."""
+    check(lib().gatmi_set_option(name.encode(), int(value)), "gatmi_set_option")
 
 
 def prof_enable(on: bool) -> None:

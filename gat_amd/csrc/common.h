@@ -108,5 +108,6 @@ int launch_gemm(const GemmDesc &d, hipStream_t st);
 bool kres_covers(const GemmDesc &d);
 int launch_kres(const GemmDesc &d, hipStream_t st);
 int device_cus();   // CUs of the current device (256 when it cannot be queried)
+int option(const char *name, int dflt);   // gatmi_set_option / environment switch, see errors.cpp
 
 }  // namespace gatmi

@@ -1,5 +1,7 @@
 // Thread-local error message and version of libgat_mi355.so.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <vector>
@@ -13,6 +15,25 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// Kernel-selection switches (A/B runs, parity tests of the fallback kernels): -1 = not set
+// here -> the environment variable of the same name decides, read at every call.
+static const char *const kOptNames[] = {"GATMI_STREAM", "GATMI_BWD2", "GATMI_KRES", "GATMI_KREG",
+                                        "GATMI_KREG_TAIL", "GATMI_DW_STREAM", "GATMI_DW_TAIL"};
+constexpr int kNumOpts = sizeof(kOptNames) / sizeof(kOptNames[0]);
+static int g_opt[kNumOpts] = {-1, -1, -1, -1, -1, -1, -1};
+static int opt_index(const char *name) {
+    for (int i = 0; i < kNumOpts; ++i)
+        if (strcmp(name, kOptNames[i]) == 0) return i;
+    return -1;
+}
+int option(const char *name, int dflt) {
+    const int i = opt_index(name);
+    if (i >= 0 && g_opt[i] >= 0) return g_opt[i];
+    const char *e = getenv(name);
+    if (e && e[0] >= '0' && e[0] <= '9') return atoi(e);
+    return dflt;
 }
 
 struct ProfRec {
@@ -38,6 +59,16 @@ void prof_end(hipStream_t st) {
     if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, st);
 }
 }  // namespace gatmi
+
+extern "C" int gatmi_set_option(const char *name, int value) {
+    const int i = name ? gatmi::opt_index(name) : -1;
+    if (i < 0) {
+        gatmi::set_error("gatmi_set_option: unknown option %s", name ? name : "(null)");
+        return GATMI_ERR_ARG;
+    }
+    gatmi::g_opt[i] = value < 0 ? -1 : value;
+    return GATMI_OK;
+}
 
 extern "C" int gatmi_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(gatmi::g_prof_mu);

@@ -1086,8 +1086,7 @@ static bool make_in_geo(const gatmi_shape &s, InGeo *g) {
 enum InKind { IN_FWD, IN_BWD };
 
 static bool bwd2_on() {   // A/B switch: GATMI_BWD2=0 runs the kernel with the chain in the row loop
-    static const char *env = getenv("GATMI_BWD2");
-    return !(env && env[0] == '0');
+    return option("GATMI_BWD2", 1) != 0;
 }
 
 template <int LH_T, int G, int T>
@@ -1134,10 +1133,10 @@ static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, h
 // from HBM and bytes in flight decide); a cache-resident table is served faster by the
 // register pipeline (lower per-edge overhead).  GATMI_STREAM=0/1 forces the choice (A/B runs).
 static bool stream_ok(const InGeo &g, int H, long long num_src, int mode) {
-    static const char *force = getenv("GATMI_STREAM");
+    const int forced = option("GATMI_STREAM", -1);
     if (!(g.G == 64 && g.Fs / 4 <= 64 && H <= kStreamMaxHeads)) return false;
-    if (mode == 2 || (mode == 0 && force && force[0] == '0')) return false;
-    if (mode == 1 || (mode == 0 && force && force[0] == '1')) return true;
+    if (mode == 2 || (mode == 0 && forced == 0)) return false;
+    if (mode == 1 || (mode == 0 && forced == 1)) return true;
     return num_src * g.Fs * 4 > (256ll << 20);
 }
 
@@ -1256,12 +1255,12 @@ struct DwPlan {
     bool tail;
 };
 static DwPlan dw_plan(int N, int H, int C, int F) {
-    static const char *env = getenv("GATMI_DW_STREAM");   // A/B switch: 0 = tiled GEMM
+    const bool stream_on = option("GATMI_DW_STREAM", 1) != 0;   // A/B switch: 0 = tiled GEMM
     DwPlan p{false, dw_splits(N, H, C, F), 0, (C + 31) / 32, (F + 31) / 32, false};
-    if (env && env[0] == '0') return p;
+    if (!stream_on) return p;
     if (p.ct > 2 || p.nt > 4 || p.ct * p.nt > 8 || N < 4096) return p;
-    static const char *envt = getenv("GATMI_DW_TAIL");   // A/B switch: 0 = a fourth 32-wide tile
-    if (p.ct == 2 && F > 96 && F <= 100 && !(envt && envt[0] == '0')) {
+    // A/B switch GATMI_DW_TAIL: 0 = a fourth 32-wide tile
+    if (p.ct == 2 && F > 96 && F <= 100 && option("GATMI_DW_TAIL", 1) != 0) {
         p.nt = 3;
         p.tail = true;
     } else if (p.nt == 3) {

@@ -646,8 +646,7 @@ static size_t kres_lds_bytes(int nf4, int NT) {
 
 // true when the K-resident kernel covers the product (else use launch_gemm)
 bool kres_covers(const GemmDesc &d) {
-    static const char *env = getenv("GATMI_KRES");   // A/B switch: 0 = tiled kernel
-    if (env && env[0] == '0') return false;
+    if (option("GATMI_KRES", 1) == 0) return false;   // A/B switch: 0 = tiled kernel
     const int ka = d.a_kpad > d.K ? d.a_kpad : d.K;  // A's zero-padded row length, if longer
     const int nf4 = ka / 4;
     const int nstore = d.n_store > d.Nn ? d.n_store : d.Nn;
@@ -720,8 +719,7 @@ static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
 // B-in-registers variant: at most 128 operand registers per lane, at least 3 tile buffers per wave
 template <int NT>
 static bool kreg_dispatch(const GemmDesc &d, int nf4, hipStream_t st) {
-    static const char *env = getenv("GATMI_KREG");   // A/B switch: 0 = B in LDS
-    if (env && env[0] == '0') return false;
+    if (option("GATMI_KREG", 1) == 0) return false;   // A/B switch: 0 = B in LDS
     const int kc = (nf4 + 1) / 2;
     if ((size_t)4 * 3 * 32 * nf4 * 16 > 160 * 1024) return false;
     if (nf4 == 16) { kreg_launch<NT, 8, true>(d, nf4, st); return true; }
@@ -735,9 +733,7 @@ static bool kreg_dispatch(const GemmDesc &d, int nf4, hipStream_t st) {
 }
 
 static bool kreg_tail3(const GemmDesc &d, int nf4, hipStream_t st) {
-    static const char *env = getenv("GATMI_KREG");
-    static const char *envt = getenv("GATMI_KREG_TAIL");
-    if ((env && env[0] == '0') || (envt && envt[0] == '0')) return false;
+    if (option("GATMI_KREG", 1) == 0 || option("GATMI_KREG_TAIL", 1) == 0) return false;
     const int kc = (nf4 + 1) / 2;
     if ((size_t)4 * 3 * 32 * nf4 * 16 > 160 * 1024) return false;
     if (nf4 == 16) { kreg_launch<3, 8, true, true>(d, nf4, st); return true; }

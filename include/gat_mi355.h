@@ -48,6 +48,11 @@ int gatmi_version(void);
  * is bracketed by HIP events on its launch stream.  gatmi_prof_read waits for the
  * recorded events, copies up to max_records (tag[32], milliseconds) pairs out (host
  * pointers), clears the list and returns the number copied. */
+/* Kernel-selection switch for A/B runs and for the parity tests of the fallback kernels
+ * (no counterpart in the reference): name = GATMI_STREAM, GATMI_BWD2, GATMI_KRES, GATMI_KREG,
+ * GATMI_KREG_TAIL, GATMI_DW_STREAM, GATMI_DW_TAIL; value 0/1, or < 0 to
+ * hand the decision back to the environment variable of the same name. */
+int gatmi_set_option(const char *name, int value);
 int gatmi_prof_enable(int on);
 int gatmi_prof_read(char *tags /* host [max_records][32] */, float *ms /* host */,
                     int max_records);

@@ -256,6 +256,29 @@ def test_input_aggregation_ragged_gemm_tiles(cuda, n, f, h, c):
             close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("option", ["GATMI_BWD2", "GATMI_KRES", "GATMI_KREG", "GATMI_KREG_TAIL",
+                                    "GATMI_DW_STREAM", "GATMI_DW_TAIL"])
+def test_fallback_kernels_match_oracle(cuda, option):
+    """Every A/B switch of DESIGN.md section 5 set to 0: the kernel it falls back to (backward with
+    the chain in the row loop, tiled GEMMs, B in LDS, a fourth 32-wide tile instead of the 4x4x1
+    tail, tiled split-K d_W) is held to the same bar on the ragged products-shaped layer."""
+    from gat_amd import _lib, synth
+    n, f, h, c = 4099, 100, 4, 64
+    ei = synth.powerlaw_graph(n, 9 * n, 700, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 1)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option(option, 0)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True)
+    finally:
+        _lib.set_option(option, -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 def test_input_aggregation_properties_at_scale(cuda):
     """products-sized table (beyond the Infinity Cache: the streaming kernel is what auto picks):
     identical rows in -> identical rows + bias out (the softmax weights of every destination sum
