@@ -1,6 +1,7 @@
 """bench.py -- GAT layer fwd+bwd edges/sec on MI355X (BASELINE.json's metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|arxiv|cora|runpy100k]
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+                  [--workload products|arxiv|cora|runpy100k|products_uniform|arxiv_uniform|cora_uniform]
 
 A step is one forward + backward of one GAT layer (projection, fused attention /
 softmax / aggregation, all gradients) over the whole synthetic graph, inputs resident
@@ -62,7 +63,13 @@ def cpu_baseline(name, seed, budget_s=25.0):
         if time.time() - t_all > budget_s:
             break
     best = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    torch.set_num_threads(1)        # "also report a 1-thread figure" (one run)
+    t0 = time.time()
+    O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    single = time.time() - t0
+    torch.set_num_threads(cores)
     return {"value": ep / best, "unit": "edges/s", "cores": cores, "kind": "port",
+            "single_thread_value": ep / single,
             "sample": f"{name}-shaped generator at scale {scale:.4f} ({n} nodes, {ep} edges after "
                       f"self-loop normalisation), oracle/gat_oracle.py fwd+bwd incl. self-loop "
                       f"normalisation, median of {max(len(times) - 1, 1)} timed runs after 1 warm-up, "

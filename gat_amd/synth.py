@@ -13,6 +13,10 @@ WORKLOADS = {
     "arxiv": (169343, 1166243, 128, 4, 64, 13000),
     "products": (2449029, 62000000, 100, 4, 64, 17000),
     "runpy100k": (100000, 500000, 25, 8, 30, 0),
+    # uniform-degree variants ("to separate skew effects"): same sizes, dst uniform
+    "products_uniform": (2449029, 62000000, 100, 4, 64, 0),
+    "arxiv_uniform": (169343, 1166243, 128, 4, 64, 0),
+    "cora_uniform": (2708, 10556, 1433, 8, 8, 0),
 }
 
 
