@@ -718,6 +718,158 @@ __global__ __launch_bounds__(256, GATMI_BWD2_OCC) void inagg_bwd2_kernel(const I
 }
 
 // ---------------------------------------------------------------------------------
+// The same pass in the "two edges per instruction" layout (H <= 4, Fp <= 128).  With head
+// groups (above) every gathered row sits H2 times in registers, so a wave keeps four rows in
+// flight and the kernel is bound by that (25 % less gather traffic buys 5 %).  Here the 32
+// lanes of a wave HALF hold one x row once (one float4 each), the two halves work on two
+// consecutive edges of the destination row, and every lane carries all heads:
+//   * one load instruction = two rows; eight pairs in flight per wave (16 rows, 32 VGPRs);
+//   * the H per-head dots of a lane are reduced by a multi-value butterfly: lanes trade half
+//     of their values with lane^1, then lane^2 (after which a lane owns head 2(l&1) + ((l>>1)&1)
+//     of its quad), then sum over the quads of the half;
+//   * d_u = c1 <q, x_j> + c0 with (c1, c0) from the hoisted chain's LDS table as above, spread
+//     to the other heads' lanes by four quad broadcasts, then the H FMAs per lane.
+// ---------------------------------------------------------------------------------
+constexpr int kBwd3U = 2;   // pairs per bank; two banks
+
+__device__ __forceinline__ float quad_heads_sum(float v0, float v1, float v2, float v3, bool o1, bool o2) {
+    float a = o1 ? v2 : v0, b = o1 ? v3 : v1;
+    const float sa = o1 ? v0 : v2, sb = o1 ? v1 : v3;
+    a += dpp_mov<0xB1>(sa);                     // quad_perm [1,0,3,2]
+    b += dpp_mov<0xB1>(sb);
+    float c = o2 ? b : a;
+    const float sc = o2 ? a : b;
+    c += dpp_mov<0x4E>(sc);                     // quad_perm [2,3,0,1]
+    c += dpp_mov<0x124>(c);                     // row_ror:4
+    c += dpp_mov<0x128>(c);                     // row_ror:8
+    return c + __shfl_xor(c, 16, 64);           // the other 16-lane row of this half
+}
+
+__global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
+    constexpr int U = kBwd3U;
+    __shared__ f2 cs_all[4][64 * 4];
+    const int lane = threadIdx.x & 63, half = lane >> 5, p = lane & 31, wv = threadIdx.x >> 6;
+    const bool o1 = lane & 1, o2 = lane & 2;
+    const int hl_raw = 2 * (int)o1 + (int)(o2 ? 1 : 0);          // the head this lane ends up owning
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    f2 *cs = cs_all[wv];                                         // [edge of the chunk][4 heads]
+    const unsigned hbit = 1u << hl;
+    f4 ys[4], yd[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) ys[h] = yd[h] = zero4();
+    const int stride = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
+        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
+        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+        end = min(end, beg + A.seg_len);
+        f4 q4[4];
+        float sv[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const bool on = pok && h < A.H;
+            q4[h] = on ? ldv4(A.q + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            const f4 z4 = on ? ldv4(A.zin + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            f2 d = {0.f, 0.f};
+            pk_dot4(d, q4[h], z4);
+            sv[h] = d.x + d.y;
+        }
+        const float S = quad_heads_sum(sv[0], sv[1], sv[2], sv[3], o1, o2);
+        const float lse_i = A.lsein[(size_t)row * A.H + hl];
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float dad = 0.f;
+        for (int c = beg; c < end; c += 64) {
+            const int n = min(64, end - c);
+            const int cl = min(lane, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + 2 * u;
+                    const int j0 = __builtin_amdgcn_readlane(cj, min(k, n - 1));
+                    const int j1 = __builtin_amdgcn_readlane(cj, min(k + 1, n - 1));
+                    const int j = half ? j1 : j0;
+                    v[u] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                }
+            };
+            f4 va[U], vb[U];
+            load(va, 0);
+            // the chain, one (edge, head) pair per lane: edge = 16 * pass + lane / 4, head = hl
+            for (int e0 = 0; e0 < n; e0 += 16) {
+                const int e = e0 + (lane >> 2);
+                const int ec = min(e, n - 1);
+                const int js = __shfl(cj, ec, 64);
+                const unsigned sb = (unsigned)__shfl(kb, ec, 64);
+                const float as = A.xs[(size_t)js * A.Fs + A.Fp + hl];
+                const float uu = as + adi;
+                const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                const float alpha = (e < n && hlok) ? exp_fast(uu * slope - lse_i) : 0.f;
+                const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
+                cs[e * 4 + hl_raw] = f2{at * slope, -alpha * S * slope};
+            }
+            auto reduce = [&](const f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ke = k0 + 2 * u + half;             // this half's edge
+                    float dv[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        f2 d = {0.f, 0.f};
+                        pk_dot4(d, v[u], q4[h]);
+                        dv[h] = d.x + d.y;
+                    }
+                    const float d2 = quad_heads_sum(dv[0], dv[1], dv[2], dv[3], o1, o2);
+                    const f2 cc = cs[min(ke, n - 1) * 4 + hl_raw];
+                    const float du = ke < n ? fmaf(d2, cc.x, cc.y) : 0.f;
+                    dad += du;
+                    pk_fma4(ys[0], dpp_mov<0x00>(du), v[u]);      // quad lane 0 owns head 0
+                    pk_fma4(ys[1], dpp_mov<0xAA>(du), v[u]);      // quad lane 2 owns head 1
+                    pk_fma4(ys[2], dpp_mov<0x55>(du), v[u]);      // quad lane 1 owns head 2
+                    pk_fma4(ys[3], dpp_mov<0xFF>(du), v[u]);      // quad lane 3 owns head 3
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 4 * U) {
+                load(vb, k0 + 2 * U);
+                reduce(va, k0);
+                load(va, k0 + 4 * U);
+                reduce(vb, k0 + 2 * U);
+            }
+        }
+        // d_wd += (sum of the row's d_u) * x_i: both halves hold partial sums of d_u
+        {
+            const float dt = dad + __shfl_xor(dad, 32, 64);
+            const f4 xi = pok ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 4) : zero4();
+            const float w = half == 0 ? 1.f : 0.f;                // count the row once
+            pk_fma4(yd[0], dpp_mov<0x00>(dt) * w, xi);
+            pk_fma4(yd[1], dpp_mov<0xAA>(dt) * w, xi);
+            pk_fma4(yd[2], dpp_mov<0x55>(dt) * w, xi);
+            pk_fma4(yd[3], dpp_mov<0xFF>(dt) * w, xi);
+        }
+    }
+    // the two halves accumulated different edges: add them, one partial row per wave
+    float *dst = A.part_y + (size_t)(blockIdx.x * 4 + wv) * 2 * HF;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ys[h][k] += __shfl_xor(ys[h][k], 32, 64);
+            yd[h][k] += __shfl_xor(yd[h][k], 32, 64);
+        }
+        if (half == 0 && pok && h < A.H) {
+            stv4(dst + h * A.Fp + p * 4, ys[h]);
+            stv4(dst + HF + h * A.Fp + p * 4, yd[h]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Small kernels around the two passes
 // ---------------------------------------------------------------------------------
 // wsd[k][h*Fp + f] = sum_c W[(h*C + c), f] * att_k[h*C + c]  (k = 0: att_src, 1: att_dst), pad = 0
@@ -1109,6 +1261,12 @@ static void in_launch_g(InKind k, const InGeo &g, const InArgs &A, int grid, hip
 static int in_grid(const InGeo &g, int n_items) { return item_grid(n_items, 256 / g.G); }
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
+    // backward, H <= 4 and a row of at most 32 float4: the two-edges-per-instruction layout
+    if (k == IN_BWD && g.G == 64 && A.H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0 && bwd2_on()) {
+        hipLaunchKernelGGL(inagg_bwd3_kernel, dim3(grid), dim3(256), 0, st, A);
+        GATMI_HIP(hipGetLastError());
+        return GATMI_OK;
+    }
     // compile-time butterflies for the layers BASELINE.json names: 100 -> 4x64 / 128 -> 4x64
     // (LH 16, T 2) and run.py's 25 -> 8x30 (LH 8, T 1)
     if (g.G == 64 && g.LH == 16 && g.T == 2) in_launch<16, 64, 2>(k, A, grid, st);
