@@ -760,9 +760,16 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
     const char *xsb = reinterpret_cast<const char *>(A.xs);
     f2 *cs = cs_all[wv];                                         // [edge of the chunk][4 heads]
     const unsigned hbit = 1u << hl;
-    f4 ys[4], yd[4];
+    // d_wd accumulates once per destination row: it lives in LDS (this wave's 4 x 128 floats,
+    // lane p of half 0 owns its float4s), not in 16 registers of the edge loop
+    __shared__ __attribute__((aligned(16))) float yd_all[4][4 * 128];
+    float *ydl = yd_all[wv];
+    f4 ys[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) ys[h] = yd[h] = zero4();
+    for (int h = 0; h < 4; ++h) {
+        ys[h] = zero4();
+        if (half == 0) stv4(ydl + h * 128 + p * 4, zero4());
+    }
     const int stride = gridDim.x * 4;
     for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
         const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
@@ -846,11 +853,17 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
         {
             const float dt = dad + __shfl_xor(dad, 32, 64);
             const f4 xi = pok ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 4) : zero4();
-            const float w = half == 0 ? 1.f : 0.f;                // count the row once
-            pk_fma4(yd[0], dpp_mov<0x00>(dt) * w, xi);
-            pk_fma4(yd[1], dpp_mov<0xAA>(dt) * w, xi);
-            pk_fma4(yd[2], dpp_mov<0x55>(dt) * w, xi);
-            pk_fma4(yd[3], dpp_mov<0xFF>(dt) * w, xi);
+            const float d0 = dpp_mov<0x00>(dt), d1 = dpp_mov<0xAA>(dt), d2h = dpp_mov<0x55>(dt),
+                        d3 = dpp_mov<0xFF>(dt);
+            if (half == 0) {                                      // count the row once
+                const float dh[4] = {d0, d1, d2h, d3};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    f4 acc = ldv4(ydl + h * 128 + p * 4);
+                    pk_fma4(acc, dh[h], xi);
+                    stv4(ydl + h * 128 + p * 4, acc);
+                }
+            }
         }
     }
     // the two halves accumulated different edges: add them, one partial row per wave
@@ -858,13 +871,10 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ys[h][k] += __shfl_xor(ys[h][k], 32, 64);
-            yd[h][k] += __shfl_xor(yd[h][k], 32, 64);
-        }
+        for (int k = 0; k < 4; ++k) ys[h][k] += __shfl_xor(ys[h][k], 32, 64);
         if (half == 0 && pok && h < A.H) {
             stv4(dst + h * A.Fp + p * 4, ys[h]);
-            stv4(dst + HF + h * A.Fp + p * 4, yd[h]);
+            stv4(dst + HF + h * A.Fp + p * 4, ldv4(ydl + h * 128 + p * 4));
         }
     }
 }
