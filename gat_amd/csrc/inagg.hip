@@ -880,6 +880,158 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
 }
 
 // ---------------------------------------------------------------------------------
+// Forward in the two-edges-per-instruction layout (H <= 4, Fp <= 128).  No dots here, so
+// once the softmax weights are hoisted the row loop is a load, one broadcast ds_read_b128 of
+// the edge's four weights and the H FMAs per lane.  The chain runs lane-parallel per 64-edge
+// chunk: lane (edge = lane / 4 + 16 pass, head = lane's quad head) computes the logit, the
+// chunk maximum and sum are butterflies over the 16 edge lanes, the running (m, s, acc) are
+// rescaled once per chunk (online softmax at chunk granularity).
+// ---------------------------------------------------------------------------------
+constexpr int kFwd3U = 4;
+
+// all-reduce over the 16 lanes of this wave that share lane & 3 (op: 0 = max, 1 = sum)
+template <int OP> __device__ __forceinline__ float edge_lanes_reduce(float v) {
+    auto comb = [](float a, float b) { return OP == 0 ? fmaxf(a, b) : a + b; };
+    v = comb(v, dpp_mov<0x124>(v));             // row_ror:4
+    v = comb(v, dpp_mov<0x128>(v));             // row_ror:8
+    v = comb(v, __shfl_xor(v, 16, 64));
+    return comb(v, __shfl_xor(v, 32, 64));
+}
+
+__global__ __launch_bounds__(256, 4) void inagg_fwd3_kernel(const InArgs A) {
+    constexpr int U = kFwd3U;
+    __shared__ __attribute__((aligned(16))) float ws_all[4][64 * 4];
+    const int lane = threadIdx.x & 63, half = lane >> 5, p = lane & 31, wv = threadIdx.x >> 6;
+    const int hl_raw = 2 * (lane & 1) + ((lane >> 1) & 1);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    float *wt = ws_all[wv];                                      // [edge of the chunk][4 heads]
+    const unsigned hbit = 1u << hl;
+    const int stride = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
+        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
+        const int slot = __builtin_amdgcn_readfirstlane(A.item_slot[it]);
+        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+        end = min(end, beg + A.seg_len);
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float m = -INFINITY, ssum = 0.f;
+        f4 acc[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc[h] = zero4();
+        for (int c = beg; c < end; c += 64) {
+            const int n = min(64, end - c);
+            const int cl = min(lane, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + 2 * u;
+                    const int j0 = __builtin_amdgcn_readlane(cj, min(k, n - 1));
+                    const int j1 = __builtin_amdgcn_readlane(cj, min(k + 1, n - 1));
+                    const int j = half ? j1 : j0;
+                    v[u] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                }
+            };
+            f4 va[U], vb[U];
+            load(va, 0);
+            // logits of the chunk, one (edge, head) pair per lane and pass
+            float zz[4];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int e = 16 * ps + (lane >> 2);
+                zz[ps] = -INFINITY;
+                if (16 * ps < n) {                                // wave-uniform
+                    const int js = __shfl(cj, min(e, n - 1), 64);
+                    const float uu = A.xs[(size_t)js * A.Fs + A.Fp + hl] + adi;
+                    zz[ps] = e < n ? (uu > 0.f ? uu : A.neg_slope * uu) : -INFINITY;
+                }
+                zmax = fmaxf(zmax, zz[ps]);
+            }
+            const float mn = fmaxf(m, edge_lanes_reduce<0>(zmax));
+            const float sc = exp_quick(m - mn);                   // first chunk: exp(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                if (16 * ps < n) {
+                    const int e = 16 * ps + (lane >> 2);
+                    const unsigned sb = (unsigned)__shfl(kb, min(e, n - 1), 64);
+                    const float pe = exp_quick(zz[ps] - mn);      // 0 past the end
+                    psum += pe;
+                    wt[e * 4 + hl_raw] = (sb & hbit) ? pe * A.inv_keep : 0.f;
+                }
+            }
+            ssum = fmaf(ssum, sc, edge_lanes_reduce<1>(psum));
+            m = mn;
+            {   // rescale the running sums: every lane needs the factor of every head
+                const float s0 = dpp_mov<0x00>(sc), s1 = dpp_mov<0xAA>(sc), s2 = dpp_mov<0x55>(sc),
+                            s3 = dpp_mov<0xFF>(sc);
+                pk_scale4(acc[0], s0);
+                pk_scale4(acc[1], s1);
+                pk_scale4(acc[2], s2);
+                pk_scale4(acc[3], s3);
+            }
+            auto reduce = [&](const f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ke = k0 + 2 * u + half;
+                    f4 w4 = *reinterpret_cast<const f4 *>(wt + min(ke, n - 1) * 4);
+                    if (ke >= n) w4 = zero4();
+                    pk_fma4(acc[0], w4[0], v[u]);
+                    pk_fma4(acc[1], w4[1], v[u]);
+                    pk_fma4(acc[2], w4[2], v[u]);
+                    pk_fma4(acc[3], w4[3], v[u]);
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 4 * U) {
+                load(vb, k0 + 2 * U);
+                reduce(va, k0);
+                load(va, k0 + 4 * U);
+                reduce(vb, k0 + 2 * U);
+            }
+        }
+        // the halves summed different edges
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[h][k] += __shfl_xor(acc[h][k], 32, 64);
+        if (slot < 0) {
+            const float inv = ssum > 0.f ? 1.0f / ssum : 0.f;
+            const float i0 = dpp_mov<0x00>(inv), i1 = dpp_mov<0xAA>(inv), i2 = dpp_mov<0x55>(inv),
+                        i3 = dpp_mov<0xFF>(inv);
+            const float iv[4] = {i0, i1, i2, i3};
+            if (half == 0 && pok) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                    if (h < A.H) {
+                        f4 o = acc[h];
+                        pk_scale4(o, iv[h]);
+                        stv4(A.z + (size_t)row * HF + h * A.Fp + p * 4, o);
+                    }
+            }
+            if (A.lse && lane < 4 && hlok) A.lse[(size_t)row * A.H + hl] = m + logf(ssum);
+        } else {
+            if (half == 0 && pok) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                    if (h < A.H) stv4(A.part_acc + (size_t)slot * HF + h * A.Fp + p * 4, acc[h]);
+            }
+            if (lane < 4 && hlok) {
+                A.part_m[(size_t)slot * A.H + hl] = m;
+                A.part_s[(size_t)slot * A.H + hl] = ssum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Small kernels around the two passes
 // ---------------------------------------------------------------------------------
 // wsd[k][h*Fp + f] = sum_c W[(h*C + c), f] * att_k[h*C + c]  (k = 0: att_src, 1: att_dst), pad = 0
@@ -1272,6 +1424,11 @@ static int in_grid(const InGeo &g, int n_items) { return item_grid(n_items, 256 
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
     // backward, H <= 4 and a row of at most 32 float4: the two-edges-per-instruction layout
+    if (k == IN_FWD && g.G == 64 && A.H <= 4 && g.lph <= 32 && option("GATMI_FWD3", 1) != 0) {
+        hipLaunchKernelGGL(inagg_fwd3_kernel, dim3(grid), dim3(256), 0, st, A);
+        GATMI_HIP(hipGetLastError());
+        return GATMI_OK;
+    }
     if (k == IN_BWD && g.G == 64 && A.H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0 && bwd2_on()) {
         hipLaunchKernelGGL(inagg_bwd3_kernel, dim3(grid), dim3(256), 0, st, A);
         GATMI_HIP(hipGetLastError());
@@ -1574,6 +1731,9 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
     A.lse = lse;
     {
         ProfScope ps("inagg_fwd", st);
+        // table beyond the Infinity Cache: the LDS-DMA streaming kernel (6.67 ms against 6.93 ms
+        // for the two-edge register layout on the products-shaped layer); else in_launch_rows
+        // picks the two-edge layout when it covers the shape (H <= 4), the head-group kernel if not
         if (stream_ok(geo, H, g->num_src, a->stream)) {
             if (int e = stream_launch_rows(IN_FWD, geo, A, stream_ws, st)) return e;
         } else if (int e = in_launch_rows(IN_FWD, geo, A, in_grid(geo, A.n_items), st)) {

@@ -256,8 +256,8 @@ def test_input_aggregation_ragged_gemm_tiles(cuda, n, f, h, c):
             close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
-@pytest.mark.parametrize("option", ["GATMI_BWD2", "GATMI_KRES", "GATMI_KREG", "GATMI_KREG_TAIL",
-                                    "GATMI_DW_STREAM", "GATMI_DW_TAIL"])
+@pytest.mark.parametrize("option", ["GATMI_BWD2", "GATMI_BWD3", "GATMI_FWD3", "GATMI_KRES", "GATMI_KREG",
+                                    "GATMI_KREG_TAIL", "GATMI_DW_STREAM", "GATMI_DW_TAIL"])
 def test_fallback_kernels_match_oracle(cuda, option):
     """Every A/B switch of DESIGN.md section 5 set to 0: the kernel it falls back to (backward with
     the chain in the row loop, tiled GEMMs, B in LDS, a fourth 32-wide tile instead of the 4x4x1
