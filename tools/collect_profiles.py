@@ -50,7 +50,7 @@ def main():
         lines.append(f"{k:28s} FETCH_SIZE: avg {f:.1f} (n={nf})  WRITE_SIZE: avg {w:.1f} (n={nw})")
         traffic[k] = int((2 * f + w) * 1024)
     open(os.path.join(dst, f"pmc_{prefix}.txt"), "w").write("\n".join(lines) + "\n")
-    tags = {"inagg_fwd": ["inagg_fwd_stream_kernel", "inagg_fwd_kernel"], "inagg_bwd_edge": ["inagg_bwd2_kernel", "inagg_bwd_kernel"],
+    tags = {"inagg_fwd": ["inagg_fwd_stream_kernel", "inagg_fwd3_kernel", "inagg_fwd_kernel"], "inagg_bwd_edge": ["inagg_bwd3_kernel", "inagg_bwd2_kernel", "inagg_bwd_kernel"],
             "attn_fwd": ["attn_fwd_kernel"], "attn_bwd_edge": ["attn_bwd_edge_kernel"]}
     old = {}
     try:    # kernels this run did not launch keep their earlier measurement
