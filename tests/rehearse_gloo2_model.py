@@ -1,13 +1,15 @@
 """2-rank gloo rehearsal of PartitionedGAT on ONE GPU (both ranks on cuda:0, HipBackend): log-probabilities,
 loss and parameter gradients of one training step against the single-process oracle network.  Not a
-pytest (two GPU processes); run as  python tools/gloo2_model.py  on a GPU box."""
+pytest (two GPU processes; the file name keeps it out of collection); run as
+python tests/rehearse_gloo2_model.py  on a GPU box.  Lives under tests/ because it checks against the oracle."""
 import os, sys
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def worker(rank, world, port, q):
