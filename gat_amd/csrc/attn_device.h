@@ -114,7 +114,11 @@ __device__ __forceinline__ float exp_fast(float x) {
 // largest).  Two instructions instead of seven; used where the exponential sits in the per-edge
 // loop of a VALU-bound kernel.
 __device__ __forceinline__ float exp_quick(float x) {   // x = -inf gives 0 (no clamp needed)
+#ifdef GATMI_EXACT_EXP
+    return exp_fast(x);
+#else
     return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f);
+#endif
 }
 
 // Attention-dropout keep decision of (edge e in dst-CSR order, head): a counter-based

@@ -1,0 +1,123 @@
+"""Size-independent properties at BASELINE.json's FULL configuration (products-shaped: 2,449,029
+nodes, 62 M edges, 100 -> 4 x 64), where the oracle cannot run: graph-layout invariants, softmax
+weights summing to one, linearity of the backward, agreement of the two layer paths and of the
+kernel variants, reproducibility of the hash dropout.  A few seconds on one MI355X."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full(cuda):
+    from gat_amd import synth
+    from gat_amd.graph import cached_graph
+    ei, n, f, h, c = synth.workload_graph("products", 0, cuda)
+    layout = cached_graph(ei, n)
+    return ei, n, f, h, c, layout
+
+
+def test_full_size_graph_layout_invariants(cuda, full):
+    ei, n, f, h, c, layout = full
+    self_loops = int((ei[0] == ei[1]).sum())
+    assert layout.num_edges == ei.size(1) - self_loops + n            # remove_self_loops + add_self_loops
+    rowptr = layout.rowptr.long()
+    assert int(rowptr[0]) == 0 and int(rowptr[-1]) == layout.num_edges
+    deg = rowptr[1:] - rowptr[:-1]
+    assert int(deg.min()) >= 1                                         # every node has its loop
+    want = torch.bincount(ei[1][ei[0] != ei[1]], minlength=n) + 1
+    assert torch.equal(deg, want)
+    # a checksum of the whole edge multiset survives the sort: sum of (src * 31 + dst) mod 2^61
+    dst = torch.repeat_interleave(torch.arange(n, device=cuda), deg)
+    got = int(((layout.col.long() * 31 + dst) % (1 << 40)).sum())
+    keep = ei[0] != ei[1]
+    loops = torch.arange(n, device=cuda)
+    ref = int(((ei[0][keep] * 31 + ei[1][keep]) % (1 << 40)).sum()) + int(((loops * 31 + loops) % (1 << 40)).sum())
+    assert got == ref
+
+
+@pytest.mark.parametrize("inagg", [True, False])
+def test_full_size_constant_rows_give_constant_output(cuda, full, inagg):
+    from gat_amd import GATConv
+    ei, n, f, h, c, _ = full
+    torch.manual_seed(1)
+    conv = GATConv(f, c, heads=h, input_aggregation=inagg).to(cuda).eval()
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(h * c, device=cuda))
+    x = torch.randn(1, f, device=cuda).expand(n, f).contiguous()
+    out = conv(x, ei)
+    expect = (x[:1] @ conv.lin.weight.t()) + conv.bias
+    err = float((out.detach() - expect.detach()).abs().max())
+    assert err <= 2e-5 * float(expect.abs().max()), err
+
+
+def test_full_size_paths_and_kernel_variants_agree(cuda, full):
+    """Projected rows against input-side aggregation, and the streaming forward against the
+    two-edge register forward, on the same random inputs: forward and every parameter gradient."""
+    from gat_amd import GATConv, _lib
+    ei, n, f, h, c, _ = full
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.randn(n, f, generator=g, device=cuda)
+    go = torch.randn(n, h * c, generator=g, device=cuda)
+    torch.manual_seed(2)
+    conv = GATConv(f, c, heads=h).to(cuda).eval()
+
+    def run(inagg, stream=None, option=None):
+        conv.input_aggregation, conv.stream = inagg, stream
+        if option:
+            _lib.set_option(option, 0)
+        try:
+            conv.zero_grad()
+            out = conv(x, ei)
+            out.backward(go)
+        finally:
+            if option:
+                _lib.set_option(option, -1)
+        return [out.detach().clone()] + [p.grad.clone() for p in conv.parameters()]
+
+    base = run(True)
+    names = ["out"] + [k for k, _ in conv.named_parameters()]
+    # Kernel variants of one path see the same fp32 logits: they agree to re-association.  The two
+    # PATHS round the logits differently (a_src = <x, W^T att> against <W x, att>), so among the 2.6e8
+    # (edge, head) pairs a handful whose logit lies within ~2e-7 of zero take the other LeakyReLU
+    # slope -- measured against the fp64 oracle at 1/10 size: 2 of 2.6e7, each worth ~1e-4 of a
+    # gradient's largest element.  That is fp32, not a kernel property (the reference's own fp32
+    # run flips its own handful): the forward is held to 3e-5, the gradients across paths to 2e-3.
+    for label, other, gtol in (("projected rows", run(False), 2e-3),
+                               ("register forward", run(True, stream=False), 3e-5),
+                               ("head-group backward", run(True, option="GATMI_BWD3"), 3e-5),
+                               ("chain in the row loop", run(True, option="GATMI_BWD2"), 3e-5)):
+        for name, a, b in zip(names, base, other):
+            scale = float(a.abs().max())
+            tol = 3e-5 if name == "out" else gtol
+            assert float((a - b).abs().max()) <= tol * scale, (label, name)
+
+
+def test_full_size_backward_is_linear_and_dropout_reproducible(cuda, full):
+    from gat_amd import GATConv
+    ei, n, f, h, c, _ = full
+    g = torch.Generator(device=cuda).manual_seed(4)
+    x = torch.randn(n, f, generator=g, device=cuda)
+    g1 = torch.randn(n, h * c, generator=g, device=cuda)
+    g2 = torch.randn(n, h * c, generator=g, device=cuda)
+    torch.manual_seed(5)
+    conv = GATConv(f, c, heads=h, dropout=0.425).to(cuda)
+
+    def grads(go, seed):
+        conv.train(); conv.zero_grad()
+        torch.manual_seed(seed)                                       # the layer draws its hash seed from torch
+        out = conv(x, ei)
+        out.backward(go)
+        return out.detach().clone(), conv.lin.weight.grad.clone(), conv.att_src.grad.clone()
+
+    o1, w1, a1 = grads(g1, 7)
+    o1b, w1b, _ = grads(g1, 7)
+    assert torch.equal(o1, o1b) and torch.equal(w1, w1b)              # same seed: same mask, same bits
+    o3, _, _ = grads(g1, 8)
+    assert not torch.equal(o1, o3)                                     # another seed: another mask
+    _, w2, a2 = grads(g2, 7)
+    _, w12, a12 = grads(g1 + 2 * g2, 7)
+    assert float((w1 + 2 * w2 - w12).abs().max() / w12.abs().max()) < 3e-5
+    assert float((a1 + 2 * a2 - a12).abs().max() / a12.abs().max()) < 3e-5
+    kept = float((o1 != o3).float().mean())
+    assert kept > 0.5                                                  # most rows see a different mask
