@@ -866,15 +866,22 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
             }
         }
     }
-    // the two halves accumulated different edges: add them, one partial row per wave
-    float *dst = A.part_y + (size_t)(blockIdx.x * 4 + wv) * 2 * HF;
+    // the two halves accumulated different edges: add them; then the block's four waves are
+    // added in LDS and ONE partial row per block goes out (part_y [blocks][2][H*Fp])
+    __shared__ __attribute__((aligned(16))) float ys_all[4][4 * 128];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) ys[h][k] += __shfl_xor(ys[h][k], 32, 64);
-        if (half == 0 && pok && h < A.H) {
-            stv4(dst + h * A.Fp + p * 4, ys[h]);
-            stv4(dst + HF + h * A.Fp + p * 4, ldv4(ydl + h * 128 + p * 4));
+        if (half == 0) stv4(ys_all[wv] + h * 128 + p * 4, ys[h]);
+    }
+    __syncthreads();
+    float *dst = A.part_y + (size_t)blockIdx.x * 2 * HF;
+    for (int idx = threadIdx.x; idx < 2 * 4 * 128; idx += 256) {
+        const int which = idx >> 9, r = idx & 511, hh = r >> 7, ff = r & 127;
+        if (hh < A.H && ff < A.Fp) {
+            const float(*src)[4 * 128] = which ? yd_all : ys_all;
+            dst[which * HF + hh * A.Fp + ff] = (src[0][r] + src[1][r]) + (src[2][r] + src[3][r]);
         }
     }
 }
@@ -1422,6 +1429,11 @@ static void in_launch_g(InKind k, const InGeo &g, const InArgs &A, int grid, hip
 
 static int in_grid(const InGeo &g, int n_items) { return item_grid(n_items, 256 / g.G); }
 
+// the two-edge backward writes one partial row per BLOCK, the others one per wave
+static bool bwd3_covers(const InGeo &g, int H) {
+    return g.G == 64 && H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0 && bwd2_on();
+}
+
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
     // backward, H <= 4 and a row of at most 32 float4: the two-edges-per-instruction layout
     if (k == IN_FWD && g.G == 64 && A.H <= 4 && g.lph <= 32 && option("GATMI_FWD3", 1) != 0) {
@@ -1429,7 +1441,7 @@ static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, h
         GATMI_HIP(hipGetLastError());
         return GATMI_OK;
     }
-    if (k == IN_BWD && g.G == 64 && A.H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0 && bwd2_on()) {
+    if (k == IN_BWD && bwd3_covers(g, A.H)) {
         hipLaunchKernelGGL(inagg_bwd3_kernel, dim3(grid), dim3(256), 0, st, A);
         GATMI_HIP(hipGetLastError());
         return GATMI_OK;
@@ -1838,8 +1850,9 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     }
     {
         ProfScope ps("inagg_colsums", st);
-        SumJob j0{w.part_y, w.dwsd, w.waves, 2 * geo.HF, geo.HF};
-        SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, w.waves, 2 * geo.HF, geo.HF};
+        const int prow = (A.n_items > 0 && bwd3_covers(geo, H)) ? w.waves / 4 : w.waves;   // partial rows written
+        SumJob j0{w.part_y, w.dwsd, prow, 2 * geo.HF, geo.HF};
+        SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, prow, 2 * geo.HF, geo.HF};
         hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0,
                            j1, j1);
         GATMI_HIP(hipGetLastError());
