@@ -20,9 +20,14 @@ void set_error(const char *fmt, ...) {
 // Kernel-selection switches (A/B runs, parity tests of the fallback kernels): -1 = not set
 // here -> the environment variable of the same name decides, read at every call.
 static const char *const kOptNames[] = {"GATMI_STREAM", "GATMI_BWD2", "GATMI_KRES", "GATMI_KREG",
-                                        "GATMI_KREG_TAIL", "GATMI_DW_STREAM", "GATMI_DW_TAIL", "GATMI_BWD3", "GATMI_FWD3"};
+                                        "GATMI_KREG_TAIL", "GATMI_DW_STREAM", "GATMI_DW_TAIL", "GATMI_BWD3", "GATMI_FWD3",
+                                        "GATMI_EDGE8"};
 constexpr int kNumOpts = sizeof(kOptNames) / sizeof(kOptNames[0]);
-static int g_opt[kNumOpts] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_opt[kNumOpts];
+static const bool g_opt_init = [] {
+    for (int &v : g_opt) v = -1;
+    return true;
+}();
 static int opt_index(const char *name) {
     for (int i = 0; i < kNumOpts; ++i)
         if (strcmp(name, kOptNames[i]) == 0) return i;

@@ -1039,6 +1039,354 @@ __global__ __launch_bounds__(256, 4) void inagg_fwd3_kernel(const InArgs A) {
 }
 
 // ---------------------------------------------------------------------------------
+// The same layout for up to 8 heads and any row of at most 32 float4: LR = 2^LRL lanes hold
+// one packed row (one float4 each), a wave instruction covers EP = 64 / LR consecutive edges,
+// all HP = 2^HPL heads sit in every lane.  run.py's 25 -> 8 x 30 layer (lph 7) runs 8 edges
+// per instruction instead of one.
+//   * per-head dots: HP partial sums per lane, HPL trading stages (a lane keeps half of its
+//     values and receives the partner's sums of that half), then an all-reduce over the
+//     remaining LR / HP lanes.  Lane l ends up owning head bitrev(l mod HP).
+//   * a head's scalar goes back to all lanes of its HP-lane cluster by one DPP (HP 4) or one
+//     ds_swizzle (HP 8) per head.
+// ---------------------------------------------------------------------------------
+template <int M> __device__ __forceinline__ float lane_xor(float v) {   // the value lane ^ M holds
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);                      // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]
+    else if constexpr (M == 4)                                          // swizzle, xor_mask 4
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));
+    else if constexpr (M == 8) return dpp_mov<0x128>(v);                // row_ror:8
+    else return __shfl_xor(v, M, 64);
+}
+
+template <int S, int HP> __device__ __forceinline__ void trade_stage(float (&v)[HP], int lane) {
+    constexpr int n2 = HP >> (S + 1);
+    const bool up = (lane >> S) & 1;
+#pragma unroll
+    for (int i = 0; i < n2; ++i) {
+        const float keep = up ? v[n2 + i] : v[i];
+        const float send = up ? v[i] : v[n2 + i];
+        v[i] = keep + lane_xor<(1 << S)>(send);
+    }
+}
+
+// v[h] = this lane's part of head h's dot; returns the whole dot of the head this lane owns
+template <int HPL, int LRL> __device__ __forceinline__ float heads_sum_e(float (&v)[1 << HPL], int lane) {
+    constexpr int HP = 1 << HPL;
+    if constexpr (HPL >= 1) trade_stage<0, HP>(v, lane);
+    if constexpr (HPL >= 2) trade_stage<1, HP>(v, lane);
+    if constexpr (HPL >= 3) trade_stage<2, HP>(v, lane);
+    float c = v[0];
+    if constexpr (HPL <= 2 && LRL > 2) c += lane_xor<4>(c);
+    if constexpr (HPL <= 3 && LRL > 3) c += lane_xor<8>(c);
+    if constexpr (LRL > 4) c += lane_xor<16>(c);
+    return c;
+}
+
+template <int HPL> __device__ __forceinline__ int head_of_lane(int lane) {
+    int h = 0;
+#pragma unroll
+    for (int s = 0; s < HPL; ++s) h |= ((lane >> s) & 1) << (HPL - 1 - s);
+    return h;
+}
+
+// head h's value, from the lane of this lane's HP-cluster that owns it
+template <int HPL> __device__ __forceinline__ float bcast_head(float v, int h) {
+    if constexpr (HPL == 2) {
+        switch (h) {
+            case 0: return dpp_mov<0x00>(v);
+            case 1: return dpp_mov<0xAA>(v);
+            case 2: return dpp_mov<0x55>(v);
+            default: return dpp_mov<0xFF>(v);
+        }
+    } else {   // swizzle: lane' = (lane & 0x18) | owner, owner = bitrev3(h)
+        const int i = __float_as_int(v);
+        switch (h) {
+            case 0: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (0 << 5)));
+            case 1: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (4 << 5)));
+            case 2: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (2 << 5)));
+            case 3: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (6 << 5)));
+            case 4: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (1 << 5)));
+            case 5: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (5 << 5)));
+            case 6: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (3 << 5)));
+            default: return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x18 | (7 << 5)));
+        }
+    }
+}
+
+// all-reduce over the lanes that differ in lane bits LOW .. 5 (OP: 0 = max, 1 = sum)
+template <int OP, int LOW> __device__ __forceinline__ float high_lanes_reduce(float v) {
+    auto comb = [](float a, float b) { return OP == 0 ? fmaxf(a, b) : a + b; };
+    if constexpr (LOW <= 2) v = comb(v, lane_xor<4>(v));
+    if constexpr (LOW <= 3) v = comb(v, lane_xor<8>(v));
+    if constexpr (LOW <= 4) v = comb(v, lane_xor<16>(v));
+    if constexpr (LOW <= 5) v = comb(v, lane_xor<32>(v));
+    return v;
+}
+
+template <int LRL, int HPL, int U>
+__global__ __launch_bounds__(256, HPL == 3 ? 3 : 4) void inagg_bwde_kernel(const InArgs A) {
+    constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, ROWF = HP * LR * 4, EPP = 64 >> HPL;
+    __shared__ f2 cs_all[4][64 * HP];
+    __shared__ __attribute__((aligned(16))) float yd_all[4][ROWF];
+    __shared__ __attribute__((aligned(16))) float ys_all[4][ROWF];
+    const int lane = threadIdx.x & 63, eg = lane >> LRL, p = lane & (LR - 1), wv = threadIdx.x >> 6;
+    const int hl_raw = head_of_lane<HPL>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    f2 *cs = cs_all[wv];                                         // [edge of the chunk][HP heads]
+    const unsigned hbit = 1u << hl;
+    float *ydl = yd_all[wv];
+    f4 ys[HP];
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+        ys[h] = zero4();
+        if (eg == 0) stv4(ydl + h * LR * 4 + p * 4, zero4());
+    }
+    const int stride = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
+        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
+        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+        end = min(end, beg + A.seg_len);
+        f4 q4[HP];
+        float sv[HP];
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+            const bool on = pok && h < A.H;
+            q4[h] = on ? ldv4(A.q + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            const f4 z4 = on ? ldv4(A.zin + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            f2 d = {0.f, 0.f};
+            pk_dot4(d, q4[h], z4);
+            sv[h] = d.x + d.y;
+        }
+        const float S = heads_sum_e<HPL, LRL>(sv, lane);
+        const float lse_i = A.lsein[(size_t)row * A.H + hl];
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float dad = 0.f;
+        for (int c = beg; c < end; c += 64) {
+            const int n = min(64, end - c);
+            const int cl = min(lane, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = __shfl(cj, min(k0 + EP * u + eg, n - 1), 64);
+                    v[u] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                }
+            };
+            f4 va[U], vb[U];
+            load(va, 0);
+            // the chain, one (edge, head) pair per lane: edge = EPP * pass + lane / HP, head = hl
+            for (int e0 = 0; e0 < n; e0 += EPP) {
+                const int e = e0 + (lane >> HPL);
+                const int ec = min(e, n - 1);
+                const int js = __shfl(cj, ec, 64);
+                const unsigned sb = (unsigned)__shfl(kb, ec, 64);
+                const float as = A.xs[(size_t)js * A.Fs + A.Fp + hl];
+                const float uu = as + adi;
+                const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                const float alpha = (e < n && hlok) ? exp_fast(uu * slope - lse_i) : 0.f;
+                const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
+                cs[e * HP + hl_raw] = f2{at * slope, -alpha * S * slope};
+            }
+            auto reduce = [&](const f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ke = k0 + EP * u + eg;              // this lane group's edge
+                    float dv[HP];
+#pragma unroll
+                    for (int h = 0; h < HP; ++h) {
+                        f2 d = {0.f, 0.f};
+                        pk_dot4(d, v[u], q4[h]);
+                        dv[h] = d.x + d.y;
+                    }
+                    const float d2 = heads_sum_e<HPL, LRL>(dv, lane);
+                    const f2 cc = cs[min(ke, n - 1) * HP + hl_raw];
+                    const float du = ke < n ? fmaf(d2, cc.x, cc.y) : 0.f;
+                    dad += du;
+#pragma unroll
+                    for (int h = 0; h < HP; ++h) pk_fma4(ys[h], bcast_head<HPL>(du, h), v[u]);
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 2 * U * EP) {
+                load(vb, k0 + U * EP);
+                reduce(va, k0);
+                load(va, k0 + 2 * U * EP);
+                reduce(vb, k0 + U * EP);
+            }
+        }
+        // d_wd += (sum of the row's d_u) * x_i: every lane group holds partial sums of d_u
+        {
+            const float dt = high_lanes_reduce<1, LRL>(dad);
+            const f4 xi = pok ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 4) : zero4();
+            float dh[HP];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) dh[h] = bcast_head<HPL>(dt, h);
+            if (eg == 0) {                                        // count the row once
+#pragma unroll
+                for (int h = 0; h < HP; ++h) {
+                    f4 acc = ldv4(ydl + h * LR * 4 + p * 4);
+                    pk_fma4(acc, dh[h], xi);
+                    stv4(ydl + h * LR * 4 + p * 4, acc);
+                }
+            }
+        }
+    }
+    // the lane groups accumulated different edges: add them; then the block's four waves are
+    // added in LDS and ONE partial row per block goes out (part_y [blocks][2][H*Fp])
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ys[h][k] = high_lanes_reduce<1, LRL>(ys[h][k]);
+        if (eg == 0) stv4(ys_all[wv] + h * LR * 4 + p * 4, ys[h]);
+    }
+    __syncthreads();
+    float *dst = A.part_y + (size_t)blockIdx.x * 2 * HF;
+    for (int idx = threadIdx.x; idx < 2 * ROWF; idx += 256) {
+        const int which = idx / ROWF, r = idx % ROWF, hh = r / (LR * 4), ff = r % (LR * 4);
+        if (hh < A.H && ff < A.Fp) {
+            const float(*src)[ROWF] = which ? yd_all : ys_all;
+            dst[which * HF + hh * A.Fp + ff] = (src[0][r] + src[1][r]) + (src[2][r] + src[3][r]);
+        }
+    }
+}
+
+template <int LRL, int HPL, int U>
+__global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
+    constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, EPP = 64 >> HPL;
+    __shared__ __attribute__((aligned(16))) float ws_all[4][64 * HP];
+    const int lane = threadIdx.x & 63, eg = lane >> LRL, p = lane & (LR - 1), wv = threadIdx.x >> 6;
+    const int hl_raw = head_of_lane<HPL>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    float *wt = ws_all[wv];                                      // [edge of the chunk][HP heads]
+    const unsigned hbit = 1u << hl;
+    const int stride = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
+        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
+        const int slot = __builtin_amdgcn_readfirstlane(A.item_slot[it]);
+        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+        end = min(end, beg + A.seg_len);
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float m = -INFINITY, ssum = 0.f;
+        f4 acc[HP];
+#pragma unroll
+        for (int h = 0; h < HP; ++h) acc[h] = zero4();
+        for (int c = beg; c < end; c += 64) {
+            const int n = min(64, end - c);
+            const int cl = min(lane, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = __shfl(cj, min(k0 + EP * u + eg, n - 1), 64);
+                    v[u] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                }
+            };
+            f4 va[U], vb[U];
+            load(va, 0);
+            // logits of the chunk, one (edge, head) pair per lane and pass
+            float zz[HP];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int ps = 0; ps < HP; ++ps) {
+                const int e = EPP * ps + (lane >> HPL);
+                zz[ps] = -INFINITY;
+                if (EPP * ps < n) {                               // wave-uniform
+                    const int js = __shfl(cj, min(e, n - 1), 64);
+                    const float uu = A.xs[(size_t)js * A.Fs + A.Fp + hl] + adi;
+                    zz[ps] = e < n ? (uu > 0.f ? uu : A.neg_slope * uu) : -INFINITY;
+                }
+                zmax = fmaxf(zmax, zz[ps]);
+            }
+            const float mn = fmaxf(m, high_lanes_reduce<0, HPL>(zmax));
+            const float sc = exp_quick(m - mn);                   // first chunk: exp(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < HP; ++ps) {
+                if (EPP * ps < n) {
+                    const int e = EPP * ps + (lane >> HPL);
+                    const unsigned sb = (unsigned)__shfl(kb, min(e, n - 1), 64);
+                    const float pe = exp_quick(zz[ps] - mn);      // 0 past the end
+                    psum += pe;
+                    wt[e * HP + hl_raw] = (sb & hbit) ? pe * A.inv_keep : 0.f;
+                }
+            }
+            ssum = fmaf(ssum, sc, high_lanes_reduce<1, HPL>(psum));
+            m = mn;
+#pragma unroll
+            for (int h = 0; h < HP; ++h) pk_scale4(acc[h], bcast_head<HPL>(sc, h));
+            auto reduce = [&](const f4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ke = k0 + EP * u + eg;
+                    const float *wp = wt + min(ke, n - 1) * HP;
+#pragma unroll
+                    for (int hq = 0; hq < HP / 4; ++hq) {
+                        f4 w4 = *reinterpret_cast<const f4 *>(wp + 4 * hq);
+                        if (ke >= n) w4 = zero4();
+                        pk_fma4(acc[4 * hq + 0], w4[0], v[u]);
+                        pk_fma4(acc[4 * hq + 1], w4[1], v[u]);
+                        pk_fma4(acc[4 * hq + 2], w4[2], v[u]);
+                        pk_fma4(acc[4 * hq + 3], w4[3], v[u]);
+                    }
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 2 * U * EP) {
+                load(vb, k0 + U * EP);
+                reduce(va, k0);
+                load(va, k0 + 2 * U * EP);
+                reduce(vb, k0 + U * EP);
+            }
+        }
+        // the lane groups summed different edges
+#pragma unroll
+        for (int h = 0; h < HP; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[h][k] = high_lanes_reduce<1, LRL>(acc[h][k]);
+        if (slot < 0) {
+            const float inv = ssum > 0.f ? 1.0f / ssum : 0.f;
+            float iv[HP];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) iv[h] = bcast_head<HPL>(inv, h);
+            if (eg == 0 && pok) {
+#pragma unroll
+                for (int h = 0; h < HP; ++h)
+                    if (h < A.H) {
+                        f4 o = acc[h];
+                        pk_scale4(o, iv[h]);
+                        stv4(A.z + (size_t)row * HF + h * A.Fp + p * 4, o);
+                    }
+            }
+            if (A.lse && lane < HP && hlok) A.lse[(size_t)row * A.H + hl] = m + logf(ssum);
+        } else {
+            if (eg == 0 && pok) {
+#pragma unroll
+                for (int h = 0; h < HP; ++h)
+                    if (h < A.H) stv4(A.part_acc + (size_t)slot * HF + h * A.Fp + p * 4, acc[h]);
+            }
+            if (lane < HP && hlok) {
+                A.part_m[(size_t)slot * A.H + hl] = m;
+                A.part_s[(size_t)slot * A.H + hl] = ssum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Small kernels around the two passes
 // ---------------------------------------------------------------------------------
 // wsd[k][h*Fp + f] = sum_c W[(h*C + c), f] * att_k[h*C + c]  (k = 0: att_src, 1: att_dst), pad = 0
@@ -1430,11 +1778,42 @@ static void in_launch_g(InKind k, const InGeo &g, const InArgs &A, int grid, hip
 static int in_grid(const InGeo &g, int n_items) { return item_grid(n_items, 256 / g.G); }
 
 // the two-edge backward writes one partial row per BLOCK, the others one per wave
+// The multi-edge layout for 5..8 heads and rows of 9..32 float4 (4 or 2 edges per instruction;
+// 2.8 against 8.3 ms on 128 -> 8x32 at degree 25).  Rows of at most 8 float4 stay with the
+// one-edge kernels: a lane holds one float4 there too, and at run.py's degree 5 the row loop is
+// a small part of an item (0.56 against 0.50 ms on runpy100k; 1.43 against 1.51 at degree 25).
+// GATMI_EDGE8=0: one-edge kernels everywhere; 2: multi-edge also for short rows and, in place
+// of the two-edge kernels, for H <= 4 (parity tests, A/B runs).
+static int edge8_lrl(const InGeo &g, int H) {
+    const int mode = option("GATMI_EDGE8", 1);
+    if (mode == 0 || g.G != 64 || g.lph > 32) return 0;
+    const int lrl = ilog2(next_pow2(g.lph));
+    if (g.H2 == 8) return lrl > 3 ? lrl : (mode == 2 ? 3 : 0);
+    if (mode == 2 && g.H2 == 4 && g.lph > 16) return 5;
+    return 0;
+}
 static bool bwd3_covers(const InGeo &g, int H) {
-    return g.G == 64 && H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0 && bwd2_on();
+    if (!bwd2_on()) return false;
+    if (edge8_lrl(g, H)) return true;
+    return g.G == 64 && H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0;
+}
+template <int LRL, int HPL, int UF, int UB>
+static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
+    if (k == IN_FWD)
+        hipLaunchKernelGGL((inagg_fwde_kernel<LRL, HPL, UF>), dim3(grid), dim3(256), 0, st, A);
+    else
+        hipLaunchKernelGGL((inagg_bwde_kernel<LRL, HPL, UB>), dim3(grid), dim3(256), 0, st, A);
 }
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
+    if (const int lrl = edge8_lrl(g, A.H); lrl && (k == IN_FWD || bwd2_on())) {
+        if (g.H2 == 4) edge8_launch<5, 2, 4, 2>(k, A, grid, st);
+        else if (lrl == 3) edge8_launch<3, 3, 1, 1>(k, A, grid, st);
+        else if (lrl == 4) edge8_launch<4, 3, 2, 2>(k, A, grid, st);
+        else edge8_launch<5, 3, 2, 2>(k, A, grid, st);
+        GATMI_HIP(hipGetLastError());
+        return GATMI_OK;
+    }
     // backward, H <= 4 and a row of at most 32 float4: the two-edges-per-instruction layout
     if (k == IN_FWD && g.G == 64 && A.H <= 4 && g.lph <= 32 && option("GATMI_FWD3", 1) != 0) {
         hipLaunchKernelGGL(inagg_fwd3_kernel, dim3(grid), dim3(256), 0, st, A);

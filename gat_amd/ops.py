@@ -144,17 +144,21 @@ def inagg_supported(in_features: int, heads: int, channels: int, edges_per_node:
         return False
     if edges_per_node is None:
         return True
-    # float4 slots per lane of the edge kernels (inagg.hip make_in_geo): beyond 2 the per-edge
-    # arithmetic, not the bytes, decides, and the projected-row kernels (1 slot) win
-    # (products-shaped 100 -> 8x30: 8.4 ms against 5.8 ms)
+    # float4 slots per lane of the one-edge kernels (inagg.hip make_in_geo): beyond 2 the
+    # per-edge arithmetic, not the bytes, decides, and the projected-row kernels (1 slot) win.
+    # The multi-edge kernels (one float4 per lane: H <= 4 or 5..8 heads, rows of <= 32 float4)
+    # have no such limit, but with 8 heads in a lane they run about 1.5x the byte model
+    # (tools/edge8_ab.py, 200k nodes, degree 25: 128 -> 8x32 2.80 ms against 2.51 ms projected,
+    # 100 -> 8x30 2.51 / 2.57, 100 -> 6x64 2.63 / 3.81; degree 7: 100 -> 8x30 1.91 / 1.50)
     h2 = 1 << (heads - 1).bit_length()
     lph = padded_channels(in_features) // 4
     lh = min(64 // h2, 1 << (lph - 1).bit_length())
-    if -(-lph // lh) > 2:
+    multi_edge = h2 <= 8 and lph <= 32 and h2 * lh == 64
+    if -(-lph // lh) > 2 and not multi_edge:
         return False
     fp = padded_channels(in_features)
     fs = fp + padded_channels(heads)
-    cost_in = 2 * edges_per_node * fs + 6 * heads * fp
+    cost_in = (2 * edges_per_node * fs + 6 * heads * fp) * (1.5 if h2 == 8 else 1.0)
     cost_rows = 2 * edges_per_node * dp + 10 * dp
     return cost_in < cost_rows
 

@@ -256,6 +256,54 @@ def test_input_aggregation_ragged_gemm_tiles(cuda, n, f, h, c):
             close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 0], ids=["default", "multi_edge", "one_edge"])
+@pytest.mark.parametrize("n,f,h,c,p", [(3001, 25, 8, 30, 0.0), (3001, 25, 8, 30, 0.4), (2500, 17, 6, 9, 0.0),
+                                       (2777, 60, 8, 16, 0.3), (2049, 128, 8, 32, 0.0),
+                                       (1999, 97, 5, 20, 0.5), (1500, 33, 7, 5, 0.0)])
+def test_input_aggregation_five_to_eight_heads(cuda, n, f, h, c, p, mode):
+    """5..8 heads: the multi-edge layout (8, 4 or 2 edges per wave instruction for rows of up to
+    8, 16, 32 float4; by default only for rows beyond 8 float4, GATMI_EDGE8=2 everywhere) and,
+    with the switch off, the one-edge kernels, on a power-law graph whose hubs are cut into
+    segments -- output and gradients against the oracle, with and without attention dropout."""
+    from gat_amd import _lib, synth
+    ei = synth.powerlaw_graph(n, 11 * n, 900, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 1)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                              mask=mask, training=p > 0)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_EDGE8", mode)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, p, mask, 256, inputs, inagg=True, stream=False)
+    finally:
+        _lib.set_option("GATMI_EDGE8", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
+def test_multi_edge_layout_four_heads(cuda):
+    """GATMI_EDGE8=2 runs the general multi-edge kernels where the two-edge kernels normally
+    run (H <= 4): same bar."""
+    from gat_amd import _lib, synth
+    n, f, h, c = 4099, 100, 4, 64
+    ei = synth.powerlaw_graph(n, 9 * n, 700, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 1)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_EDGE8", 2)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True, stream=False)
+    finally:
+        _lib.set_option("GATMI_EDGE8", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 @pytest.mark.parametrize("option", ["GATMI_BWD2", "GATMI_BWD3", "GATMI_FWD3", "GATMI_KRES", "GATMI_KREG",
                                     "GATMI_KREG_TAIL", "GATMI_DW_STREAM", "GATMI_DW_TAIL"])
 def test_fallback_kernels_match_oracle(cuda, option):
