@@ -1387,6 +1387,262 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
 }
 
 // ---------------------------------------------------------------------------------
+// A destination row per 8-lane group (5..8 heads, rows of at most 8 float4, LOW degree: run.py's
+// 25 -> 8x30 layer on a 5-nearest-neighbour graph).  With one row per wave an item there is a
+// handful of edges under a whole wave's prologue.  Here a wave takes 8 items at once: the 8
+// lanes of group g hold one packed row (a float4 each) and all 8 heads, lane p of a group owns
+// head bitrev(p) for the scalar chain, 8 edges of the group's row make a chunk (lane p loads
+// col and keep bits of edge p).  Nothing crosses between groups until the partial sums of the
+// backward are added at the end; the wave loops to its longest row.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int groups_max_i(int v) {
+    v = max(v, __shfl_xor(v, 8, 64));
+    v = max(v, __shfl_xor(v, 16, 64));
+    return max(v, __shfl_xor(v, 32, 64));
+}
+
+#ifndef GATMI_FWDG_OCC
+#define GATMI_FWDG_OCC 3
+#endif
+#ifndef GATMI_BWDG_OCC
+#define GATMI_BWDG_OCC 3
+#endif
+__global__ __launch_bounds__(256, GATMI_FWDG_OCC) void inagg_fwdg_kernel(const InArgs A) {
+    const int lane = threadIdx.x & 63, g = lane >> 3, p = lane & 7, wv = threadIdx.x >> 6;
+    const int hl_raw = head_of_lane<3>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    const unsigned hbit = 1u << hl;
+    const int stride = gridDim.x * 32;
+    for (int it0 = (xcd_contiguous_block() * 4 + wv) * 8; it0 < A.n_items; it0 += stride) {
+        const int it = it0 + g;
+        const bool on = it < A.n_items;
+        int row = 0, beg = 0, end = 0, slot = -1;
+        if (on) {
+            row = A.item_row[it];
+            beg = A.item_beg[it];
+            slot = A.item_slot[it];
+            end = min(A.rowptr[row + 1], beg + A.seg_len);
+        }
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float m = -INFINITY, ssum = 0.f;
+        f4 acc[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) acc[h] = zero4();
+        const int nmax = __builtin_amdgcn_readfirstlane(groups_max_i(end - beg));
+        for (int c = 0; c < nmax; c += 8) {
+            const int n = min(max(end - beg - c, 0), 8);          // this group's edges of the chunk
+            const int nw = min(nmax - c, 8);                      // the wave's longest
+            const int el = beg + c + min(p, max(n - 1, 0));
+            const int cj = n > 0 ? A.col[el] : 0;
+            const int kb = n > 0 ? (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)el, A.H) : 0;
+            f4 v[8];
+            float z[8];
+            unsigned sb[8];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                z[e] = -INFINITY;
+                if (e < nw) {                                     // wave-uniform
+                    const int src = (lane & 56) | min(e, max(n - 1, 0));
+                    const int j = __shfl(cj, src, 64);
+                    sb[e] = (unsigned)__shfl(kb, src, 64);
+                    v[e] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                    const float uu = A.xs[(size_t)j * A.Fs + A.Fp + hl] + adi;
+                    z[e] = e < n ? (uu > 0.f ? uu : A.neg_slope * uu) : -INFINITY;
+                }
+                zmax = fmaxf(zmax, z[e]);
+            }
+            const float mn = fmaxf(m, zmax);
+            const float sc = mn == -INFINITY ? 1.0f : exp_quick(m - mn);
+            float psum = 0.f, w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                w[e] = 0.f;
+                if (e < nw) {
+                    const float pe = e < n ? exp_quick(z[e] - mn) : 0.f;
+                    psum += pe;
+                    w[e] = (sb[e] & hbit) ? pe * A.inv_keep : 0.f;
+                }
+            }
+            ssum = fmaf(ssum, sc, psum);
+            m = mn;
+            if (c > 0) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) pk_scale4(acc[h], bcast_head<3>(sc, h));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < nw) {
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) pk_fma4(acc[h], bcast_head<3>(w[e], h), v[e]);
+                }
+        }
+        const float inv = ssum > 0.f ? 1.0f / ssum : 0.f;
+        float iv[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) iv[h] = bcast_head<3>(inv, h);
+        if (on && slot < 0) {
+            if (pok) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    if (h < A.H) {
+                        f4 o = acc[h];
+                        pk_scale4(o, iv[h]);
+                        stv4(A.z + (size_t)row * HF + h * A.Fp + p * 4, o);
+                    }
+            }
+            if (A.lse && hlok) A.lse[(size_t)row * A.H + hl] = m + logf(ssum);
+        } else if (on) {
+            if (pok) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    if (h < A.H) stv4(A.part_acc + (size_t)slot * HF + h * A.Fp + p * 4, acc[h]);
+            }
+            if (hlok) {
+                A.part_m[(size_t)slot * A.H + hl] = m;
+                A.part_s[(size_t)slot * A.H + hl] = ssum;
+            }
+        }
+    }
+}
+
+#ifndef GATMI_BWDG_E
+#define GATMI_BWDG_E 2
+#endif
+constexpr int kBwdgE = GATMI_BWDG_E;
+__global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const InArgs A) {
+    constexpr int ROWF = 8 * 8 * 4;                               // [8 heads][8 lanes x float4]
+    __shared__ f4 yd_all[4][8 * 64];                              // [wave][head][lane]
+    __shared__ __attribute__((aligned(16))) float red_all[2][4][ROWF];
+    const int lane = threadIdx.x & 63, g = lane >> 3, p = lane & 7, wv = threadIdx.x >> 6;
+    const int hl_raw = head_of_lane<3>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    const unsigned hbit = 1u << hl;
+    f4 *ydl = yd_all[wv];
+    f4 ys[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        ys[h] = zero4();
+        ydl[h * 64 + lane] = zero4();
+    }
+    const int stride = gridDim.x * 32;
+    for (int it0 = (xcd_contiguous_block() * 4 + wv) * 8; it0 < A.n_items; it0 += stride) {
+        const int it = it0 + g;
+        const bool on = it < A.n_items;
+        int row = 0, beg = 0, end = 0;
+        if (on) {
+            row = A.item_row[it];
+            beg = A.item_beg[it];
+            end = min(A.rowptr[row + 1], beg + A.seg_len);
+        }
+        f4 q4[8];
+        float sv[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const bool ld = on && pok && h < A.H;
+            q4[h] = ld ? ldv4(A.q + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            const f4 z4 = ld ? ldv4(A.zin + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            f2 d = {0.f, 0.f};
+            pk_dot4(d, q4[h], z4);
+            sv[h] = d.x + d.y;
+        }
+        const float S = heads_sum_e<3, 3>(sv, lane);
+        const float lse_i = A.lsein[(size_t)row * A.H + hl];
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float dad = 0.f;
+        const int nmax = __builtin_amdgcn_readfirstlane(groups_max_i(end - beg));
+        for (int c = 0; c < nmax; c += 8) {
+            const int n = min(max(end - beg - c, 0), 8);
+            const int nw = min(nmax - c, 8);
+            const int el = beg + c + min(p, max(n - 1, 0));
+            const int cj = n > 0 ? A.col[el] : 0;
+            const int kb = n > 0 ? (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)el, A.H) : 0;
+            for (int e0 = 0; e0 < nw; e0 += kBwdgE) {             // kBwdgE rows in flight
+                f4 v[kBwdgE];
+                float as[kBwdgE];
+                unsigned sb[kBwdgE];
+#pragma unroll
+                for (int e = 0; e < kBwdgE; ++e)
+                    if (e0 + e < nw) {                            // wave-uniform
+                        const int src = (lane & 56) | min(e0 + e, max(n - 1, 0));
+                        const int j = __shfl(cj, src, 64);
+                        sb[e] = (unsigned)__shfl(kb, src, 64);
+                        v[e] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                        as[e] = A.xs[(size_t)j * A.Fs + A.Fp + hl];
+                    }
+#pragma unroll
+                for (int e = 0; e < kBwdgE; ++e)
+                    if (e0 + e < nw) {
+                        // the chain of (this edge, the head this lane owns)
+                        const float uu = as[e] + adi;
+                        const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                        const float alpha = (e0 + e < n && hlok) ? exp_fast(uu * slope - lse_i) : 0.f;
+                        const float at = (sb[e] & hbit) ? alpha * A.inv_keep : 0.f;
+                        float dv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            f2 d = {0.f, 0.f};
+                            pk_dot4(d, v[e], q4[h]);
+                            dv[h] = d.x + d.y;
+                        }
+                        const float d2 = heads_sum_e<3, 3>(dv, lane);
+                        const float du = slope * (at * d2 - alpha * S);
+                        dad += du;
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) pk_fma4(ys[h], bcast_head<3>(du, h), v[e]);
+                    }
+            }
+        }
+        // d_wd += (sum of the row's d_u) * x_i
+        {
+            const f4 xi = (on && pok) ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 4) : zero4();
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float dh = bcast_head<3>(dad, h);
+                f4 acc = ydl[h * 64 + lane];
+                pk_fma4(acc, dh, xi);
+                ydl[h * 64 + lane] = acc;
+            }
+        }
+    }
+    // add the 8 groups, then the block's four waves in LDS: ONE partial row per block
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        f4 yd = ydl[h * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ys[h][k] = high_lanes_reduce<1, 3>(ys[h][k]);
+            yd[k] = high_lanes_reduce<1, 3>(yd[k]);
+        }
+        if (g == 0) {
+            stv4(red_all[0][wv] + h * 32 + p * 4, ys[h]);
+            stv4(red_all[1][wv] + h * 32 + p * 4, yd);
+        }
+    }
+    __syncthreads();
+    float *dst = A.part_y + (size_t)blockIdx.x * 2 * HF;
+    for (int idx = threadIdx.x; idx < 2 * ROWF; idx += 256) {
+        const int which = idx / ROWF, r = idx % ROWF, hh = r / 32, ff = r % 32;
+        if (hh < A.H && ff < A.Fp) {
+            const float(*src)[ROWF] = red_all[which];
+            dst[which * HF + hh * A.Fp + ff] = (src[0][r] + src[1][r]) + (src[2][r] + src[3][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Small kernels around the two passes
 // ---------------------------------------------------------------------------------
 // wsd[k][h*Fp + f] = sum_c W[(h*C + c), f] * att_k[h*C + c]  (k = 0: att_src, 1: att_dst), pad = 0
@@ -1797,6 +2053,19 @@ static bool bwd3_covers(const InGeo &g, int H) {
     if (edge8_lrl(g, H)) return true;
     return g.G == 64 && H <= 4 && g.lph <= 32 && option("GATMI_BWD3", 1) != 0;
 }
+// A destination row per 8-lane group: 5..8 heads, rows of at most 8 float4, items of few edges
+// (GATMI_GROUPROWS=0 off, 2 whatever the degree).
+static bool group_rows(const InGeo &g, const InArgs &A) {
+    const int mode = option("GATMI_GROUPROWS", 1);
+    if (mode == 0 || g.G != 64 || g.H2 != 8 || g.lph > 8 || !bwd2_on()) return false;
+    if (mode == 2) return true;
+    return A.n_items > 0 && (long long)A.E <= 12ll * A.n_items;
+}
+// these kernels take 32 items per block and pass
+static int group_rows_grid(const InArgs &A, int grid) {
+    const int need = item_grid(A.n_items, 32);
+    return need < grid ? need : grid;
+}
 template <int LRL, int HPL, int UF, int UB>
 static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
     if (k == IN_FWD)
@@ -1806,6 +2075,13 @@ static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
 }
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
+    if (group_rows(g, A)) {
+        const int gg = group_rows_grid(A, grid);
+        if (k == IN_FWD) hipLaunchKernelGGL(inagg_fwdg_kernel, dim3(gg), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(inagg_bwdg_kernel, dim3(gg), dim3(256), 0, st, A);
+        GATMI_HIP(hipGetLastError());
+        return GATMI_OK;
+    }
     if (const int lrl = edge8_lrl(g, A.H); lrl && (k == IN_FWD || bwd2_on())) {
         if (g.H2 == 4) edge8_launch<5, 2, 4, 2>(k, A, grid, st);
         else if (lrl == 3) edge8_launch<3, 3, 1, 1>(k, A, grid, st);
@@ -2229,7 +2505,9 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     }
     {
         ProfScope ps("inagg_colsums", st);
-        const int prow = (A.n_items > 0 && bwd3_covers(geo, H)) ? w.waves / 4 : w.waves;   // partial rows written
+        int prow = w.waves;                                       // partial rows written
+        if (A.n_items > 0 && group_rows(geo, A)) prow = group_rows_grid(A, w.waves / 4);
+        else if (A.n_items > 0 && bwd3_covers(geo, H)) prow = w.waves / 4;
         SumJob j0{w.part_y, w.dwsd, prow, 2 * geo.HF, geo.HF};
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, prow, 2 * geo.HF, geo.HF};
         hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0,

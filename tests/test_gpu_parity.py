@@ -275,10 +275,44 @@ def test_input_aggregation_five_to_eight_heads(cuda, n, f, h, c, p, mode):
                                               mask=mask, training=p > 0)
     summand = float(go.abs().max() * (x @ w.t()).abs().max())
     _lib.set_option("GATMI_EDGE8", mode)
+    _lib.set_option("GATMI_GROUPROWS", 0)
     try:
         out, g = run_layer(cuda, ei, n, f, h, c, p, mask, 256, inputs, inagg=True, stream=False)
     finally:
         _lib.set_option("GATMI_EDGE8", -1)
+        _lib.set_option("GATMI_GROUPROWS", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
+@pytest.mark.parametrize("graph", ["knn5", "powerlaw", "star"])
+@pytest.mark.parametrize("n,f,h,c,p", [(3001, 25, 8, 30, 0.0), (3001, 25, 8, 30, 0.425), (2500, 17, 6, 9, 0.3),
+                                       (1777, 32, 5, 16, 0.0), (9, 25, 8, 30, 0.0)])
+def test_input_aggregation_row_per_lane_group(cuda, n, f, h, c, p, graph):
+    """The kernels that give each 8-lane group its own destination row (5..8 heads, rows of at
+    most 8 float4; picked by themselves on low-degree graphs, forced here on the others): a
+    5-neighbour graph as /root/reference/gat/converter.py:7-15 emits, a power-law graph with hub
+    rows cut into segments next to one-edge rows in the same wave, and a star."""
+    from gat_amd import _lib, synth
+    if graph == "knn5":
+        ei = synth.out_degree_k_graph(n, 5, seed=n)
+    elif graph == "powerlaw":
+        ei = synth.powerlaw_graph(n, 11 * n, max(n // 3, 4), seed=n)
+    else:
+        ei = torch.stack([torch.arange(n), torch.zeros(n, dtype=torch.long)])
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 1)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                              mask=mask, training=p > 0)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_GROUPROWS", 2)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, p, mask, 64, inputs, inagg=True, stream=False)
+    finally:
+        _lib.set_option("GATMI_GROUPROWS", -1)
     close(out, ref_out, "out")
     for k in g:
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
