@@ -162,6 +162,305 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
         }
 }
 
+// ---------------------------------------------------------------------------------
+// The same product for the shapes the hidden layers have (tile 128 x 128, operands with
+// 16-byte aligned rows): float4 global loads along the contiguous dimension, two LDS buffers
+// so the next tile is stored while this one is multiplied (one barrier per K-tile instead of
+// two), K-tiles of 32, and a flattened grid whose logical order is XCD-contiguous with the
+// tiles that share an operand (the n-tiles of an m-tile; the four tiles of a d_W split) next to
+// each other, so the shared operand comes out of that XCD's L2.
+// Both operand images are written with ds_write_b128 and read conflict-free (see the kernel):
+// transposing a k-contiguous source into [k][m] with four scalar stores per float4 cost 10-15 %.
+// ---------------------------------------------------------------------------------
+constexpr int BK2 = 32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool FIX>
+__global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const float *__restrict__ A, int lda,
+                                                             const float *__restrict__ B, int ldb,
+                                                             float *__restrict__ C, int ldc, int M,
+                                                             int Nn, int K, int k_per_split,
+                                                             const AFix fix, const GemmBatch gb,
+                                                             int tiles_m, int tiles_n, int total) {
+    constexpr int BM = 128, BN = 128, MI = 2, NJ = 2;
+    // LDS images: a source contiguous in m is kept k-major, [k][132]; one contiguous in k is kept
+    // as it comes, [m][36] -- both are written with ds_write_b128
+    constexpr int SK = 132, SM = 36;
+    constexpr int NV = BM * BK2 / 4 / 256;                        // float4 per thread and operand: 4
+    constexpr int ASZ = A_KMAJOR ? BK2 * SK : BM * SM, BSZ = B_KMAJOR ? BK2 * SK : BN * SM;
+    __shared__ __attribute__((aligned(16))) float As[2][ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
+    const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (L >= total) return;
+    const int tn = L % tiles_n, tm = (L / tiles_n) % tiles_m, bz = L / (tiles_n * tiles_m);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)tm * BM;
+    const int n0 = tn * BN;
+    const int split = bz % gb.nsplit, batch = bz / gb.nsplit;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    A += (size_t)batch * gb.sA;
+    B += (size_t)batch * gb.sB;
+    C += (size_t)batch * gb.sC + (size_t)split * gb.sSplit;
+    const float *bias = gb.bias ? gb.bias + (size_t)batch * gb.sBias : nullptr;
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging maps: a source contiguous in k -> (row = idx / 8, q = idx % 8: k = 4 q ..);
+    //               a source contiguous in m -> (m4 = idx % 32, k = idx / 32)
+    f32x4 ra[NV], rb[NV], asum = {0.f, 0.f, 0.f, 0.f};
+    float rd[NV];
+    f32x4 att_fix[A_KMAJOR ? 1 : NV];
+    int fix_head = 0;
+    if (A_KMAJOR && FIX) {
+        const long long gm = m0 + 4 * (tid & 31);
+        att_fix[0] = gm < M ? *reinterpret_cast<const f32x4 *>(fix.att_p + gm) : f32x4{0.f, 0.f, 0.f, 0.f};
+        fix_head = gm < M ? (int)gm / fix.Cp : 0;
+    }
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            if (A_KMAJOR) {
+                const long long gm = m0 + 4 * (idx & 31);
+                const int gk = k0 + (idx >> 5);
+                const bool ok = gm < M && gk < kend;
+                ra[i] = ok ? *reinterpret_cast<const f32x4 *>(A + (size_t)gk * lda + gm) : f32x4{0.f, 0.f, 0.f, 0.f};
+                asum += ra[i];
+                if (FIX) rd[i] = ok ? fix.da_dst[(size_t)gk * fix.H + fix_head] : 0.f;
+            } else {
+                const long long gm = m0 + (idx >> 3);
+                const int gk = k0 + 4 * (idx & 7);
+                const bool ok = gm < M && gk < kend;
+                ra[i] = ok ? *reinterpret_cast<const f32x4 *>(A + (size_t)gm * lda + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (FIX) {
+                    rd[i] = ok ? fix.da_dst[(size_t)gm * fix.H + gk / fix.Cp] : 0.f;
+                    att_fix[A_KMAJOR ? 0 : i] =
+                        ok ? *reinterpret_cast<const f32x4 *>(fix.att_p + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            if (B_KMAJOR) {
+                const int gn = n0 + 4 * (idx & 31);
+                const int gk = k0 + (idx >> 5);
+                const bool ok = gn < Nn && gk < kend;
+                rb[i] = ok ? *reinterpret_cast<const f32x4 *>(B + (size_t)gk * ldb + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int gn = n0 + (idx >> 3);
+                const int gk = k0 + 4 * (idx & 7);
+                const bool ok = gn < Nn && gk < kend;
+                rb[i] = ok ? *reinterpret_cast<const f32x4 *>(B + (size_t)gn * ldb + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    // Whole K-tiles take this path: no bounds tests (a row or column past the edge is clamped to
+    // the last valid one -- what it produces lands in rows that are never stored and in columns
+    // the epilogue writes as zeros), a block-uniform base that advances per tile and per-thread
+    // byte offsets fixed for the kernel.  The tests and 64-bit address arithmetic of fetch()
+    // were ~150 instructions per tile and wave; with every block of the grid in the same phase
+    // nothing hides them.
+    unsigned offA[NV], offB[NV], offD[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (A_KMAJOR) {
+            const long long gm = min(m0 + 4 * (idx & 31), (long long)M - 4);
+            offA[i] = (unsigned)(((size_t)(idx >> 5) * lda + gm) * 4);
+            offD[i] = (unsigned)(((idx >> 5) * fix.H + fix_head) * 4);
+        } else {
+            const long long r = min(m0 + (idx >> 3), (long long)M - 1) - m0;
+            offA[i] = (unsigned)(((size_t)r * lda + 4 * (idx & 7)) * 4);
+            offD[i] = (unsigned)(r * fix.H * 4);
+        }
+        if (B_KMAJOR) {
+            const int gn = min(n0 + 4 * (idx & 31), Nn - 4);
+            offB[i] = (unsigned)(((size_t)(idx >> 5) * ldb + gn) * 4);
+        } else {
+            const int r = min(n0 + (idx >> 3), Nn - 1);           // absolute: n0 may lie in the zero pad
+            offB[i] = (unsigned)(((size_t)r * ldb + 4 * (idx & 7)) * 4);
+        }
+    }
+    auto fetch_whole = [&](int k0) {
+        const char *pa = reinterpret_cast<const char *>(A_KMAJOR ? A + (size_t)k0 * lda : A + (size_t)m0 * lda + k0);
+        const char *pb = reinterpret_cast<const char *>(B_KMAJOR ? B + (size_t)k0 * ldb : B + k0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4 *>(pa + offA[i]);
+            if (A_KMAJOR) asum += ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(pb + offB[i]);
+        if (FIX) {
+            if (A_KMAJOR) {
+                const char *pd = reinterpret_cast<const char *>(fix.da_dst + (size_t)k0 * fix.H);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) rd[i] = *reinterpret_cast<const float *>(pd + offD[i]);
+            } else {
+                const int gk = k0 + 4 * (tid & 7);                // the same four columns for every i
+                const char *pd = reinterpret_cast<const char *>(fix.da_dst + (size_t)m0 * fix.H);
+                const unsigned hoff = (unsigned)(gk / fix.Cp) * 4u;
+                const f32x4 att = *reinterpret_cast<const f32x4 *>(fix.att_p + gk);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    rd[i] = *reinterpret_cast<const float *>(pd + offD[i] + hoff);
+                    att_fix[A_KMAJOR ? 0 : i] = att;
+                }
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        float *as = As[buf], *bs = Bs[buf];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            f32x4 v = ra[i];
+            if (FIX) v += rd[i] * att_fix[A_KMAJOR ? 0 : i];
+            if (A_KMAJOR) *reinterpret_cast<f32x4 *>(as + (idx >> 5) * SK + 4 * (idx & 31)) = v;
+            else *reinterpret_cast<f32x4 *>(as + (idx >> 3) * SM + 4 * (idx & 7)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            if (B_KMAJOR) *reinterpret_cast<f32x4 *>(bs + (idx >> 5) * SK + 4 * (idx & 31)) = rb[i];
+            else *reinterpret_cast<f32x4 *>(bs + (idx >> 3) * SM + 4 * (idx & 7)) = rb[i];
+        }
+    };
+    auto compute = [&](int buf) {
+        // Contraction order: step (j, i), j < 8, i < 4, multiplies k = 8 j + i in lane half 0 and
+        // k = 8 j + 4 + i in half 1 -- a [m][k] image hands a lane its four k of a j as ONE
+        // ds_read_b128 (chunk 2 j + half), a [k][m] image as four rows.  The operands of j + 1 are
+        // requested before the 16 MFMAs of j issue and waited for after them (inline asm and
+        // sched_barrier pin that order: hipcc sinks ordinary reads to their use).
+        const int half = lane >> 5, l31 = lane & 31;
+        const unsigned a_addr =
+            (unsigned)(uintptr_t)((const __attribute__((address_space(3))) float *)As[buf]) +
+            4u * (A_KMAJOR ? (4 * half) * SK + wm * 64 + l31 : (wm * 64 + l31) * SM + 4 * half);
+        const unsigned b_addr =
+            (unsigned)(uintptr_t)((const __attribute__((address_space(3))) float *)Bs[buf]) +
+            4u * (B_KMAJOR ? (4 * half) * SK + wn * 64 + l31 : (wn * 64 + l31) * SM + 4 * half);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        // the asm outputs themselves are what the waits below are tied to: nothing may touch
+        // them in between (a repack here would be scheduled before the data has landed)
+        struct Ops { f32x4 v[2]; f32x2 r[4]; };                   // [m][k] image: v[tile][i]; [k][m]: r[i][tile]
+        auto ldop = [&](Ops &o, unsigned base, bool kmajor, int j) {
+            if (kmajor) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(o.r[i]) : "v"(base + (8 * j + i) * (SK * 4)));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(o.v[t]) : "v"(base + t * (32 * SM * 4) + j * 32));
+            }
+        };
+        auto mfma16 = [&](const Ops &a, const Ops &b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            A_KMAJOR ? a.r[i][mi] : a.v[mi][i], B_KMAJOR ? b.r[i][nj] : b.v[nj][i], acc[mi][nj], 0, 0, 0);
+        };
+        auto wait_ops = [&](Ops &a, Ops &b) {
+            if (A_KMAJOR && B_KMAJOR)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]),
+                             "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]));
+            else if (B_KMAJOR)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]),
+                             "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(b.v[0]), "+v"(b.v[1]));
+        };
+        Ops a0, b0, a1, b1;
+        ldop(a0, a_addr, A_KMAJOR, 0);
+        ldop(b0, b_addr, B_KMAJOR, 0);
+        wait_ops(a0, b0);
+#pragma unroll
+        for (int j = 0; j < BK2 / 8; j += 2) {
+            ldop(a1, a_addr, A_KMAJOR, j + 1);
+            ldop(b1, b_addr, B_KMAJOR, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_ops(a1, b1);
+            if (j + 2 < BK2 / 8) {
+                ldop(a0, a_addr, A_KMAJOR, j + 2);
+                ldop(b0, b_addr, B_KMAJOR, j + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 2 < BK2 / 8)
+                wait_ops(a0, b0);
+        }
+    };
+    // Whole tiles run in a loop of their own and a last partial tile (K not a multiple of 32)
+    // after it: with both fetch paths inside one loop their results meet in copies at the join,
+    // and hipcc waits for the loads there instead of after the MFMAs.
+    const int nwhole = kbeg < kend ? (kend - kbeg) / BK2 : 0;
+    const bool part = kbeg < kend && (kend - kbeg) % BK2 != 0;
+    int buf = 0;
+    if (nwhole > 0) {
+        fetch_whole(kbeg);
+        stage(0);
+    } else if (part) {
+        fetch(kbeg);
+        stage(0);
+    }
+    __syncthreads();
+    for (int t = 1; t < nwhole; ++t, buf ^= 1) {
+        fetch_whole(kbeg + t * BK2);                              // in flight during the MFMAs
+        compute(buf);
+        stage(buf ^ 1);                                           // the buffer read one tile ago
+        __syncthreads();
+    }
+    if (nwhole > 0 && part) {
+        fetch(kbeg + nwhole * BK2);
+        compute(buf);
+        stage(buf ^ 1);
+        __syncthreads();
+        compute(buf ^ 1);
+    } else if (nwhole > 0 || part) {
+        compute(buf);
+    }
+    if (A_KMAJOR && gb.asum && tn == 0) {
+        // column sums of this block's A slice: thread tid staged columns 4 (tid % 32) .. + 3
+        __shared__ f32x4 red[256];
+        red[tid] = asum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < M) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[(tid >> 2) + 32 * q][tid & 3];
+            gb.asum[(size_t)bz * M + m0 + tid] = s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cn = n0 + wn * 64 + j * 32 + (lane & 31);
+            const float bv = (bias && cn < Nn) ? bias[cn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long cm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (cm < M && cn < gb.n_store) C[(size_t)cm * ldc + cn] = cn < Nn ? acc[i][j][r] + bv : 0.f;
+            }
+        }
+}
+
 // Wp[(h*Cp + c), f] = c < C ? W[(h*C + c), f] : 0
 __global__ void pad_weight_kernel(const float *w, float *wp, int H, int C, int Cp, int F) {
     const long long tot = (long long)H * Cp * F;
@@ -772,8 +1071,41 @@ static void launch_tile(const GemmDesc &d, int kps, hipStream_t st) {
                        d.ldb, d.C, d.ldc, d.M, d.Nn, d.K, kps, d.fix, gb);
 }
 
+// gemm_f32_v2_kernel: full-size tiles, every float4 of an operand inside one row and aligned
+static bool v2_covers(const GemmDesc &d) {
+    if (option("GATMI_GEMM_V2", 1) == 0) return false;
+    if (d.M <= 64 || d.n_store <= 64 || d.lda % 4 || d.ldb % 4 || d.sA % 4 || d.sB % 4) return false;
+    if (d.Nn < 4 || d.lda > (1 << 20) || d.ldb > (1 << 20)) return false;   // 32-bit offsets inside a tile
+    if (!d.b_kmajor && (long long)d.Nn * d.ldb >= (1ll << 29)) return false;   // and over an n-major B
+    if ((!d.a_kmajor || !d.b_kmajor) && d.K % 4) return false;   // a float4 along k
+    if (((uintptr_t)d.A | (uintptr_t)d.B) & 15) return false;
+    if (d.a_kmajor && d.M % 4) return false;
+    if (d.b_kmajor && d.Nn % 4) return false;
+    if (d.fix.da_dst && (d.fix.Cp % 4 || ((uintptr_t)d.fix.att_p & 15))) return false;
+    return true;
+}
+
+template <bool AK, bool BK_>
+static void launch_v2(const GemmDesc &d, hipStream_t st) {
+    const int kps = ((d.K + d.nsplit - 1) / d.nsplit + BK2 - 1) / BK2 * BK2;
+    const int tm = (d.M + 127) / 128, tn = (d.n_store + 127) / 128;
+    const long long total = (long long)tm * tn * d.nsplit * d.nbatch;
+    const int grid = (int)((total + 7) / 8 * 8);
+    GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, d.nsplit, d.n_store, d.asum};
+    if (d.fix.da_dst)
+        hipLaunchKernelGGL((gemm_f32_v2_kernel<AK, BK_, true>), dim3(grid), dim3(256), 0, st, d.A, d.lda,
+                           d.B, d.ldb, d.C, d.ldc, d.M, d.Nn, d.K, kps, d.fix, gb, tm, tn, (int)total);
+    else
+        hipLaunchKernelGGL((gemm_f32_v2_kernel<AK, BK_, false>), dim3(grid), dim3(256), 0, st, d.A, d.lda,
+                           d.B, d.ldb, d.C, d.ldc, d.M, d.Nn, d.K, kps, d.fix, gb, tm, tn, (int)total);
+}
+
 template <bool AK, bool BK_>
 static void launch_layout(const GemmDesc &d, int kps, hipStream_t st) {
+    if (v2_covers(d)) {
+        launch_v2<AK, BK_>(d, st);
+        return;
+    }
     const bool m64 = d.M <= 64, n64 = d.n_store <= 64;
     if (m64 && n64) launch_tile<AK, BK_, 64, 64>(d, kps, st);
     else if (m64) launch_tile<AK, BK_, 64, 128>(d, kps, st);

@@ -318,6 +318,31 @@ def test_input_aggregation_row_per_lane_group(cuda, n, f, h, c, p, graph):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("v2", [1, 0], ids=["double_buffered", "tiled"])
+@pytest.mark.parametrize("n,f,h,c", [(1000, 100, 8, 30), (777, 256, 8, 32), (4100, 132, 4, 64),
+                                     (300, 36, 3, 33), (2049, 240, 8, 30), (130, 68, 2, 40)])
+def test_projection_gemm_variants(cuda, n, f, h, c, v2):
+    """Projected-row path with x carrying a gradient (h = x W^T, d_x with the deferred
+    destination-logit term, split-K d_W): the double-buffered float4 GEMM of the hidden-layer
+    shapes and, with GATMI_GEMM_V2=0, the tiled kernel it replaces.  K = F and K = H*Cp with and
+    without a partial last K-tile, node counts that leave the last row tile ragged, channel
+    counts padded inside a head (C = 30, 33: zero columns of the padded rows)."""
+    from gat_amd import _lib, synth
+    ei = synth.powerlaw_graph(n, 7 * n, 300, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 2)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_GEMM_V2", v2)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs)
+    finally:
+        _lib.set_option("GATMI_GEMM_V2", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 def test_multi_edge_layout_four_heads(cuda):
     """GATMI_EDGE8=2 runs the general multi-edge kernels where the two-edge kernels normally
     run (H <= 4): same bar."""
