@@ -6,7 +6,7 @@ out = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_
        "# bench.py --steps 2 --warmup 1, products-shaped.  GRBM_GUI_ACTIVE is summed over the 8 XCDs;",
        "# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)  (v_mfma_f32_32x32x2_f32 = 64 busy cycles)"]
 for v, label in (("auto", "input-side aggregation path (gemm_kreg<2,13,false,false>: out = Z W^T | gemm_kreg<3,8,true,true>: q = g W | inagg_dw_stream<2,3,true>: dW = g^T Z)"),
-                 ("off", "projected-row path (gemm_f32<false,false,..>: h = x W^T | gemm_f32<true,true,..>: dW = d_h^T x)")):
+                 ("off", "projected-row path (gemm_f32_v2<false,false,false>: h = x W^T | gemm_f32_v2<true,true,true>: dW = d_h^T x)")):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(f"gpurun_out/pmc_mfma_{v}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
