@@ -1145,6 +1145,29 @@ static int launch_gemm(bool a_km, bool b_km, const float *A, int lda, const floa
     return launch_gemm(d, st);
 }
 
+// out = sum of nsplit slabs of n4 float4 each (split-K forward of a small graph)
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const f32x4 *slab, int nsplit, long long n4,
+                                                         f32x4 *out) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+        f32x4 s = slab[i];
+        for (int k = 1; k < nsplit; ++k) s += slab[(size_t)k * n4 + i];
+        out[i] = s;
+    }
+}
+
+// h = x W^T of a SMALL graph with many features (Cora: 2708 x 1433 -> 64) is 22 tiles of 90
+// serial K-steps on 22 of 256 CUs: cut K so that ~256 blocks run, partial products into the
+// slab region of the workspace (sized for d_W), then one summing pass.
+static int fwd_splits(int N, int Dp, int F, size_t slab_floats) {
+    const long long blocks = ((N + 127) / 128) * (long long)((Dp + 127) / 128);
+    if (blocks >= 128 || F < 256 || (size_t)N * Dp % 4) return 1;
+    long long want = 256 / blocks;
+    if (want > F / 128) want = F / 128;
+    const long long fit = (long long)(slab_floats / ((size_t)N * Dp));
+    if (want > fit) want = fit;
+    return want < 2 ? 1 : (int)want;
+}
+
 static int dweight_splits(int N, int Dp, int F) {
     const int tiles = ((Dp + 127) / 128) * ((F + 127) / 128);
     int want = 512 / tiles;   // ~512 blocks: enough to fill 256 CUs, half the slab traffic of 1024
@@ -1196,7 +1219,22 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
     GATMI_HIP(hipGetLastError());
     {
         ProfScope ps("proj_fwd_gemm", st);
-        if (int e = launch_gemm(false, false, x, F, wp, F, hp, Dp, N, Dp, F, 1, st)) return e;
+        const size_t slab_floats = (size_t)dweight_splits(N, Dp, F) * Dp * F;
+        const int nsplit = fwd_splits(N, Dp, F, slab_floats);
+        if (nsplit > 1) {
+            // workspace: padded weight | padded att_dst | slab
+            float *slab = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)Dp * F * 4) +
+                                                    align_up((size_t)Dp * 4));
+            if (int e = launch_gemm(false, false, x, F, wp, F, slab, Dp, N, Dp, F, nsplit, st)) return e;
+            const long long n4 = (long long)N * Dp / 4;
+            const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st,
+                               reinterpret_cast<const f32x4 *>(slab), nsplit, n4,
+                               reinterpret_cast<f32x4 *>(hp));
+            GATMI_HIP(hipGetLastError());
+        } else if (int e = launch_gemm(false, false, x, F, wp, F, hp, Dp, N, Dp, F, 1, st)) {
+            return e;
+        }
     }
     if (a_dst) {
         ProfScope ps("proj_row_dots", st);
