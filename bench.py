@@ -123,6 +123,8 @@ def main():
     d = h * c
     g = torch.Generator(device=dev).manual_seed(args.seed)
     x = torch.randn(n, f, generator=g, device=dev)
+    hidden = args.workload.endswith("_hidden")   # a hidden layer: x has a gradient, d_x is part of the step
+    x.requires_grad_(hidden)
     torch.manual_seed(args.seed)
     conv = GATConv(f, c, heads=h, dropout=args.dropout,
                    input_aggregation={"auto": None, "on": True, "off": False}[args.input_aggregation]
@@ -138,6 +140,7 @@ def main():
 
     def step():
         conv.zero_grad(set_to_none=True)
+        x.grad = None
         out = conv(x, ei)
         out.backward(go)
 
@@ -176,7 +179,8 @@ def main():
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
                                   f"{ei.size(1)} edges ({ep} after self-loop normalisation), "
-                                  f"one GAT layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
+                                  f"one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
+                                  f"attention dropout {args.dropout} (train mode)",
                       "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
                       "parallelism": "single GPU",
                       "path": "input-side aggregation" if "inagg_fwd" in avg else "projected rows",

@@ -1645,6 +1645,21 @@ __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const I
 // ---------------------------------------------------------------------------------
 // Small kernels around the two passes
 // ---------------------------------------------------------------------------------
+// Block-diagonal weight of a group of G heads, k-major: out[m][hh*C + c][hh2*Fp + f] =
+// W[(m*G + hh)*C + c, f] when hh == hh2 and f < F, else 0.  With C not a multiple of 4 the rows of
+// one head of grad_out are not 16-byte aligned; those of a group of G = 4 / gcd(C, 4) heads are,
+// and q = g W for the group is one aligned product of K = G C by G Fp columns.
+__global__ void inagg_bdiag_kernel(const float *w, int H, int C, int F, int Fp, int G, float *out) {
+    const int K = G * C, Nn = G * Fp;
+    const long long tot = (long long)(H / G) * K * Nn;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Nn), k = (int)((i / Nn) % K), m = (int)(i / ((long long)Nn * K));
+        const int hh = k / C, c = k % C, hh2 = n / Fp, f = n % Fp;
+        out[i] = (hh == hh2 && f < F) ? w[((size_t)(m * G + hh) * C + c) * F + f] : 0.f;
+    }
+}
+
 // wsd[k][h*Fp + f] = sum_c W[(h*C + c), f] * att_k[h*C + c]  (k = 0: att_src, 1: att_dst), pad = 0
 __global__ void inagg_wsd_kernel(const float *w, const float *att_src, const float *att_dst, int H,
                                  int C, int F, int Fp, float *wsd) {
@@ -2433,7 +2448,7 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
 
 namespace {
 struct InBwdWs {
-    float *q, *part_y, *dwsd, *slab, *gsum;
+    float *q, *part_y, *dwsd, *slab, *gsum, *bdiag;
     int waves, nsplit;
     size_t bytes;
 };
@@ -2448,6 +2463,7 @@ InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &ge
     w.nsplit = dw_plan(g->num_dst, s->heads, s->channels, s->in_features).nsplit;
     w.slab = cv.take<float>((size_t)w.nsplit * s->heads * s->channels * s->in_features);
     w.gsum = cv.take<float>((size_t)w.nsplit * s->heads * s->channels);
+    w.bdiag = cv.take<float>((size_t)s->heads * s->channels * 4 * geo.Fp);   // head groups of <= 4
     w.bytes = cv.off + 256;
     return w;
 }
@@ -2487,7 +2503,23 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         d.M = N; d.Nn = F; d.K = C; d.n_store = geo.Fp; d.nbatch = H; d.nsplit = 1;
         d.bias = nullptr; d.sBias = 0;
         d.fix = AFix{nullptr, nullptr, 1, 1};
-        if (int e = kres_covers(d) ? launch_kres(d, st) : launch_gemm(d, st)) return e;
+        // C % 4 != 0 (run.py's 8 x 30): per-head rows of grad_out are unaligned for the
+        // K-resident kernels; groups of G heads are aligned (GATMI_QGROUP=0: per head, tiled)
+        const int G = C % 4 == 0 ? 1 : (C % 2 == 0 ? 2 : 4);
+        GemmDesc dg = d;
+        dg.sA = (long long)G * C;
+        dg.B = w.bdiag; dg.ldb = G * geo.Fp; dg.sB = (long long)G * C * G * geo.Fp;
+        dg.sC = (long long)G * geo.Fp;
+        dg.Nn = G * geo.Fp; dg.K = G * C; dg.n_store = G * geo.Fp; dg.nbatch = H / G;
+        if (G > 1 && H % G == 0 && option("GATMI_QGROUP", 1) != 0 && kres_covers(dg)) {
+            const long long tot = (long long)H * C * G * geo.Fp;
+            hipLaunchKernelGGL(inagg_bdiag_kernel, dim3((unsigned)((tot + 255) / 256 > 256 ? 256 : (tot + 255) / 256)),
+                               dim3(256), 0, st, a->weight, H, C, F, geo.Fp, G, w.bdiag);
+            GATMI_HIP(hipGetLastError());
+            if (int e = launch_kres(dg, st)) return e;
+        } else if (int e = kres_covers(d) ? launch_kres(d, st) : launch_gemm(d, st)) {
+            return e;
+        }
     }
     A.q = w.q;
     A.zin = z;

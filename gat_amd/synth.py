@@ -13,6 +13,12 @@ WORKLOADS = {
     "arxiv": (169343, 1166243, 128, 4, 64, 13000),
     "products": (2449029, 62000000, 100, 4, 64, 17000),
     "runpy100k": (100000, 500000, 25, 8, 30, 0),
+    "runpy10k": (10000, 50000, 25, 8, 30, 0),
+    "runpy1m": (1000000, 5000000, 25, 8, 30, 0),
+    # hidden layers of the 3-layer networks of SURVEY.md 8 (x carries a gradient: bench.py also
+    # times d_x): 256 -> 4x64 on the arxiv- and products-shaped graphs
+    "arxiv_hidden": (169343, 1166243, 256, 4, 64, 13000),
+    "products_hidden": (2449029, 62000000, 256, 4, 64, 17000),
     # uniform-degree variants ("to separate skew effects"): same sizes, dst uniform
     "products_uniform": (2449029, 62000000, 100, 4, 64, 0),
     "arxiv_uniform": (169343, 1166243, 128, 4, 64, 0),

@@ -343,6 +343,28 @@ def test_projection_gemm_variants(cuda, n, f, h, c, v2):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("grouped", [1, 0], ids=["head_groups", "per_head"])
+@pytest.mark.parametrize("n,f,h,c", [(4101, 25, 8, 30), (4200, 20, 4, 15), (4300, 30, 6, 10), (4150, 25, 3, 30)])
+def test_input_aggregation_unaligned_channel_rows(cuda, n, f, h, c, grouped):
+    """C not a multiple of 4: q = g W runs per group of 2 (C even) or 4 (C odd) heads against a
+    block-diagonal weight, so that the rows of grad_out it stages are 16-byte aligned; H = 3
+    with C = 30 cannot be grouped and, like GATMI_QGROUP=0, takes the per-head tiled product."""
+    from gat_amd import _lib, synth
+    ei = synth.powerlaw_graph(n, 6 * n, 400, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 3)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_QGROUP", grouped)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True)
+    finally:
+        _lib.set_option("GATMI_QGROUP", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 def test_multi_edge_layout_four_heads(cuda):
     """GATMI_EDGE8=2 runs the general multi-edge kernels where the two-edge kernels normally
     run (H <= 4): same bar."""
