@@ -365,6 +365,28 @@ def test_input_aggregation_unaligned_channel_rows(cuda, n, f, h, c, grouped):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("v2", [1, 0], ids=["double_buffered", "tiled"])
+@pytest.mark.parametrize("n,f,h,c", [(300, 60, 2, 96), (5000, 100, 2, 96), (700, 160, 3, 72), (4500, 132, 2, 128)])
+def test_input_aggregation_wide_channels(cuda, n, f, h, c, v2):
+    """More than 64 channels per head (and F > 128): out = Z W^T, q = g W and the split-K d_W with
+    its column sums for d_bias leave the register-resident kernels for the batched tiled GEMMs
+    -- both generations of them."""
+    from gat_amd import _lib, synth
+    ei = synth.powerlaw_graph(n, 6 * n, 300, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 5)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_GEMM_V2", v2)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True, stream=False)
+    finally:
+        _lib.set_option("GATMI_GEMM_V2", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 def test_multi_edge_layout_four_heads(cuda):
     """GATMI_EDGE8=2 runs the general multi-edge kernels where the two-edge kernels normally
     run (H <= 4): same bar."""
