@@ -99,6 +99,7 @@ struct GemmDesc {
     float *C; int ldc; long long sC, sSplit;
     int M, Nn, K, n_store, nbatch, nsplit;
     int a_kpad;   // K-resident kernel only: A rows are zero padded to this many columns (0: K)
+    bool even_ok; // K-resident kernel only: take an even number of float4 per A row (LDS reads 2-way conflicted)
     const float *bias; long long sBias;
     AFix fix;
     float *asum;   // see GemmBatch

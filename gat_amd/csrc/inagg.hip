@@ -2385,6 +2385,7 @@ extern "C" size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const ga
     cv.take<float>(slots * s->heads);
     cv.take<float>(slots * geo.HF);
     cv.take<int>(stream_ws_ints(g));   // chunk queue + table of the streaming kernel
+    cv.take<float>((size_t)s->heads * s->channels * 4 * geo.Fp);   // block-diagonal weight of head groups
     return cv.off + 256;
 }
 
@@ -2409,6 +2410,7 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
     A.part_s = cv.take<float>(slots * H);
     A.part_acc = cv.take<float>(slots * geo.HF);
     int *stream_ws = cv.take<int>(stream_ws_ints(g));
+    float *bdiag = cv.take<float>((size_t)H * C * 4 * geo.Fp);
     A.z = z;
     A.lse = lse;
     {
@@ -2441,7 +2443,28 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
         d.bias = a->bias; d.sBias = C;
         d.fix = AFix{nullptr, nullptr, 1, 1};
         d.a_kpad = geo.Fp;   // the padded columns of Z are zero
-        if (int e = kres_covers(d) ? launch_kres(d, st) : launch_gemm(d, st)) return e;
+        // tiny heads (run.py's 28 x 30): a 32-row tile is 14 MFMAs under a tile's fixed waits and
+        // stores; pairs of heads against the block-diagonal weight (the image inagg_bdiag_kernel
+        // builds reads as n-major [G C][G Fp]) halve the tiles: 0.57 -> 0.47 ms at 10^6 nodes, but
+        // 0.046 -> 0.061 ms at 10^5 (one more launch, half the blocks), hence the size test.
+        // GATMI_OUTGROUP=0: per head; 2: pairs whatever the size
+        GemmDesc dg = d;
+        const int G = 2;
+        dg.sA = (long long)G * geo.Fp;
+        dg.B = bdiag; dg.ldb = G * geo.Fp; dg.sB = (long long)G * C * G * geo.Fp;
+        dg.sC = (long long)G * C; dg.sBias = (long long)G * C;
+        dg.Nn = G * C; dg.K = G * geo.Fp; dg.a_kpad = G * geo.Fp; dg.n_store = G * C; dg.nbatch = H / G;
+        dg.even_ok = true;
+        const int og = option("GATMI_OUTGROUP", 1);
+        if (geo.Fp <= 32 && C <= 32 && H % G == 0 && (og == 2 || (og == 1 && N >= 300000)) && kres_covers(dg)) {
+            const long long tot = (long long)H * C * G * geo.Fp;
+            hipLaunchKernelGGL(inagg_bdiag_kernel, dim3((unsigned)((tot + 255) / 256 > 256 ? 256 : (tot + 255) / 256)),
+                               dim3(256), 0, st, a->weight, H, C, F, geo.Fp, G, bdiag);
+            GATMI_HIP(hipGetLastError());
+            if (int e = launch_kres(dg, st)) return e;
+        } else if (int e = kres_covers(d) ? launch_kres(d, st) : launch_gemm(d, st)) {
+            return e;
+        }
     }
     return GATMI_OK;
 }

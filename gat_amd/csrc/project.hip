@@ -951,7 +951,7 @@ bool kres_covers(const GemmDesc &d) {
     const int nstore = d.n_store > d.Nn ? d.n_store : d.Nn;
     if (d.a_kmajor || d.nsplit > 1 || d.K < 1 || ka > 128 || (ka & 3) || nstore > 128) return false;
     if ((d.lda & 3) || (d.sA & 3) || (reinterpret_cast<uintptr_t>(d.A) & 15) || d.fix.da_dst) return false;
-    if (!((nf4 & 1) || nf4 == 16)) return false;     // conflict-free LDS image: odd stride or swizzle
+    if (!((nf4 & 1) || nf4 == 16 || (d.even_ok && nf4 <= 16))) return false;   // conflict-free LDS image: odd stride or swizzle
     if (d.nbatch > 65535 || d.M < 4096) return false;
     return kres_lds_bytes(nf4, nstore <= 32 ? 1 : (nstore <= 64 ? 2 : 4)) <= 160 * 1024;
 }

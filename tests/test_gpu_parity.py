@@ -356,10 +356,12 @@ def test_input_aggregation_unaligned_channel_rows(cuda, n, f, h, c, grouped):
     ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
     summand = float(go.abs().max() * (x @ w.t()).abs().max())
     _lib.set_option("GATMI_QGROUP", grouped)
+    _lib.set_option("GATMI_OUTGROUP", 2 if grouped else 0)   # pairs of tiny heads in out = Z W^T too
     try:
         out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True)
     finally:
         _lib.set_option("GATMI_QGROUP", -1)
+        _lib.set_option("GATMI_OUTGROUP", -1)
     close(out, ref_out, "out")
     for k in g:
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
