@@ -22,7 +22,8 @@ void set_error(const char *fmt, ...) {
 static const char *const kOptNames[] = {"GATMI_STREAM", "GATMI_BWD2", "GATMI_KRES", "GATMI_KREG",
                                         "GATMI_KREG_TAIL", "GATMI_DW_STREAM", "GATMI_DW_TAIL", "GATMI_BWD3", "GATMI_FWD3",
                                         "GATMI_EDGE8", "GATMI_GROUPROWS",
-                                        "GATMI_GEMM_V2", "GATMI_QGROUP", "GATMI_OUTGROUP"};
+                                        "GATMI_GEMM_V2", "GATMI_QGROUP", "GATMI_OUTGROUP",
+                                        "GATMI_KREG_WIDE"};
 constexpr int kNumOpts = sizeof(kOptNames) / sizeof(kOptNames[0]);
 static int g_opt[kNumOpts];
 static const bool g_opt_init = [] {

@@ -951,7 +951,10 @@ bool kres_covers(const GemmDesc &d) {
     const int nstore = d.n_store > d.Nn ? d.n_store : d.Nn;
     if (d.a_kmajor || d.nsplit > 1 || d.K < 1 || ka > 128 || (ka & 3) || nstore > 128) return false;
     if ((d.lda & 3) || (d.sA & 3) || (reinterpret_cast<uintptr_t>(d.A) & 15) || d.fix.da_dst) return false;
-    if (!((nf4 & 1) || nf4 == 16 || (d.even_ok && nf4 <= 16))) return false;   // conflict-free LDS image: odd stride or swizzle
+    // conflict-free LDS image: odd stride or swizzle; 128-column rows (nf4 32) only fit the
+    // B-in-registers kernel, with two tile buffers per wave and at most 64 output columns
+    const bool wide = nf4 == 32 && nstore <= 64 && option("GATMI_KREG", 1) != 0 && option("GATMI_KREG_WIDE", 1) != 0;
+    if (!((nf4 & 1) || nf4 == 16 || wide || (d.even_ok && nf4 <= 16))) return false;
     if (d.nbatch > 65535 || d.M < 4096) return false;
     return kres_lds_bytes(nf4, nstore <= 32 ? 1 : (nstore <= 64 ? 2 : 4)) <= 160 * 1024;
 }
@@ -1020,6 +1023,10 @@ template <int NT>
 static bool kreg_dispatch(const GemmDesc &d, int nf4, hipStream_t st) {
     if (option("GATMI_KREG", 1) == 0) return false;   // A/B switch: 0 = B in LDS
     const int kc = (nf4 + 1) / 2;
+    if (nf4 == 32) {   // K = 128: two 16-KiB tile buffers per wave
+        if constexpr (NT <= 2) { kreg_launch<NT, 16, true>(d, nf4, st); return true; }
+        return false;
+    }
     if ((size_t)4 * 3 * 32 * nf4 * 16 > 160 * 1024) return false;
     if (nf4 == 16) { kreg_launch<NT, 8, true>(d, nf4, st); return true; }
     if (kc <= 4) { kreg_launch<NT, 4, false>(d, nf4, st); return true; }
@@ -1048,7 +1055,7 @@ int launch_kres(const GemmDesc &d0, hipStream_t st) {
     if (d.M == 0 || d.Nn == 0) return GATMI_OK;
     GATMI_REQUIRE(kres_covers(d), "K-resident GEMM does not cover this product");
     const int nf4 = (d.a_kpad > d.K ? d.a_kpad : d.K) / 4;
-    const bool swz = nf4 == 16;
+    const bool swz = nf4 == 16 || nf4 == 32;
     if (d.n_store > 96 && d.n_store <= 100 && kreg_tail3(d, nf4, st)) {
         // three 32-wide tiles + a 4-column tail (F = 100: the products-shaped layer)
     } else if (d.n_store <= 32) {
