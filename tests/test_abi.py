@@ -61,6 +61,21 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.check(rc, "gatmi_graph_sizes_query")
 
 
+def test_kernel_switches_documented_and_known_to_the_library():
+    """Every A/B switch DESIGN.md names is one gatmi_set_option accepts (no GPU needed: the
+    call only stores a value), and an unknown name is an argument error."""
+    import os
+    import re
+    design = open(os.path.join(os.path.dirname(__file__), "..", "DESIGN.md")).read()
+    names = sorted(set(re.findall(r"`(GATMI_[A-Z0-9_]+)=", design)) - {"GATMI_LIB", "GATMI_EXACT_EXP", "GATMI_RING"})
+    assert len(names) >= 12, names
+    for name in names:
+        _lib.set_option(name, 0)
+        _lib.set_option(name, -1)
+    with pytest.raises(RuntimeError):
+        _lib.set_option("GATMI_NO_SUCH_SWITCH", 1)
+
+
 def test_layer_refuses_cpu_tensors():
     import torch
     from gat_amd import GATConv
