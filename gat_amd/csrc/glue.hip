@@ -18,7 +18,8 @@
 
 namespace gatmi {
 
-constexpr int kGlueBlocks = 512;
+constexpr int kGlueBlocks = 2048;
+constexpr int kFinCols = 4;   // glue_stats_finalize_kernel: columns per block (64 row groups walk the partials)
 
 struct GlueArgs {
     const float *x, *gy;
@@ -119,13 +120,14 @@ __global__ __launch_bounds__(256) void glue_stats_kernel(const GlueArgs A) {
     }
 }
 
-// Chan's combination of the per-block (n_b, mean_b, M2_b), in double.  One block per 16 columns:
-// 16 row groups each take every 16th partial row, fixed-order adds through LDS.
+// Chan's combination of the per-block (n_b, mean_b, M2_b), in double.  One block per kFinCols
+// columns: 256 / kFinCols row groups each take every such partial row, fixed-order adds through LDS.
 __global__ __launch_bounds__(256) void glue_stats_finalize_kernel(
     const float *partial, int nblocks, long long rows, int cols, int nslot, float eps, float momentum,
     float *save_mean, float *save_rstd, float *running_mean, float *running_var) {
     __shared__ double red[256];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+    constexpr int CG = kFinCols, RG = 256 / CG;   // columns per block, row groups
+    const int c = blockIdx.x * CG + (threadIdx.x & (CG - 1)), rg = threadIdx.x / CG;
     const bool on = c < cols;
     const long long per = (rows + nblocks - 1) / nblocks;
     const int ld = 2 * nslot * 4;
@@ -135,16 +137,16 @@ __global__ __launch_bounds__(256) void glue_stats_finalize_kernel(
     };
     double w = 0.0;
     if (on)
-        for (int b = rg; b < nblocks; b += 16) w += nb(b) * partial[(size_t)b * ld + c];
+        for (int b = rg; b < nblocks; b += RG) w += nb(b) * partial[(size_t)b * ld + c];
     red[threadIdx.x] = w;
     __syncthreads();
     double wsum = 0.0;
-    for (int q = 0; q < 16; ++q) wsum += red[(threadIdx.x & 15) + q * 16];
+    for (int q = 0; q < RG; ++q) wsum += red[(threadIdx.x & (CG - 1)) + q * CG];
     const double mean = rows > 0 ? wsum / (double)rows : 0.0;
     __syncthreads();
     double m = 0.0;
     if (on)
-        for (int b = rg; b < nblocks; b += 16) {
+        for (int b = rg; b < nblocks; b += RG) {
             const double n = nb(b);
             if (n > 0.0) {
                 const double d = partial[(size_t)b * ld + c] - mean;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void glue_stats_finalize_kernel(
     __syncthreads();
     if (rg == 0 && on) {
         double m2 = 0.0;
-        for (int q = 0; q < 16; ++q) m2 += red[threadIdx.x + q * 16];
+        for (int q = 0; q < RG; ++q) m2 += red[threadIdx.x + q * CG];
         const double var = rows > 0 ? m2 / (double)rows : 0.0;
         save_mean[c] = (float)mean;
         save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -240,16 +242,17 @@ __global__ __launch_bounds__(256) void glue_sum_partials_kernel(const float *par
                                                                 int cols, int nslot, float *dsum) {
     __shared__ float red[256];
     const int k = blockIdx.y;
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+    constexpr int CG = kFinCols, RG = 256 / CG;
+    const int c = blockIdx.x * CG + (threadIdx.x & (CG - 1)), rg = threadIdx.x / CG;
     const size_t ld = (size_t)2 * nslot * 4;
     float s = 0.f;
     if (c < cols)
-        for (int b = rg; b < nblocks; b += 16) s += partial[(size_t)b * ld + (size_t)k * nslot * 4 + c];
+        for (int b = rg; b < nblocks; b += RG) s += partial[(size_t)b * ld + (size_t)k * nslot * 4 + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (rg == 0 && c < cols) {
         float tot = 0.f;
-        for (int q = 0; q < 16; ++q) tot += red[threadIdx.x + q * 16];
+        for (int q = 0; q < RG; ++q) tot += red[threadIdx.x + q * CG];
         dsum[(size_t)k * cols + c] = tot;
     }
 }
@@ -352,7 +355,7 @@ extern "C" int gatmi_glue_fwd(const gatmi_glue *g, const float *x, float *y, flo
         ProfScope ps("glue_stats", st);
         GATMI_REQUIRE(g->rows > 0, "glue: training-mode BatchNorm over zero rows");
         hipLaunchKernelGGL(glue_stats_kernel, dim3(blocks), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(glue_stats_finalize_kernel, dim3((g->cols + 15) / 16), dim3(256), 0, st,
+        hipLaunchKernelGGL(glue_stats_finalize_kernel, dim3((g->cols + kFinCols - 1) / kFinCols), dim3(256), 0, st,
                            A.partial, blocks,
                            (long long)g->rows, g->cols, A.nslot, g->eps, g->momentum, save_mean,
                            save_rstd, g->running_mean, g->running_var);
@@ -399,7 +402,7 @@ extern "C" int gatmi_glue_bwd(const gatmi_glue *g, const float *x, const float *
     {
         ProfScope ps("glue_reduce_bwd", st);
         if (g->rows > 0) hipLaunchKernelGGL(glue_reduce_bwd_kernel, dim3(blocks), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(glue_sum_partials_kernel, dim3((g->cols + 15) / 16, 2), dim3(256), 0, st,
+        hipLaunchKernelGGL(glue_sum_partials_kernel, dim3((g->cols + kFinCols - 1) / kFinCols, 2), dim3(256), 0, st,
                            A.partial, g->rows > 0 ? blocks : 0, g->cols, A.nslot, dsum);
         GATMI_HIP(hipGetLastError());
     }
