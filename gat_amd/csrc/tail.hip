@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float *__restrict__
 
 static int tail_geometry(long long rows, int K, int *lpr, int *blocks) {
     int l = 1;
-    while (l < K && l < 64) l <<= 1;
+    while (l * kTailV < K && l < 64) l <<= 1;   // a lane takes up to kTailV classes: 40 classes -> 16 lanes per row
     *lpr = l;
     const long long need = (rows + 256 / l - 1) / (256 / l);
     *blocks = (int)(need < 1 ? 1 : (need > kTailBlocks ? kTailBlocks : need));

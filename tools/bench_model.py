@@ -48,7 +48,7 @@ def main():
     tot = sum(r.device_time_total for r in rows)
     ours = sum(r.device_time_total for r in rows if "gatmi" in r.key or "rocprim" in r.key)
     print(f"device time/epoch {tot / 3e3:.3f} ms, libgat_mi355 kernels {100 * ours / tot:.1f} %")
-    for r in rows[:14]:
+    for r in rows[:26]:
         print(f"  {r.device_time_total / 3e3:8.3f} ms  {r.count // 3:4d}x  {r.key[:90]}")
 
 
