@@ -121,3 +121,50 @@ def test_full_size_backward_is_linear_and_dropout_reproducible(cuda, full):
     assert float((a1 + 2 * a2 - a12).abs().max() / a12.abs().max()) < 3e-5
     kept = float((o1 != o3).float().mean())
     assert kept > 0.5                                                  # most rows see a different mask
+
+
+def test_runpy_shaped_million_nodes(cuda):
+    """run.py's input layer 25 -> 8x30 on 10^6 nodes with 5 out-edges each (the graph
+    /root/reference/gat/converter.py:7-15 emits, at the largest size SURVEY.md 8d names): the
+    row-per-lane-group edge kernels, q = g W and out = Z W^T per pair of heads (the latter only
+    runs from 3*10^5 rows).  Constant rows in -> x W^T + b out; parameter gradients linear in
+    grad_out; and the same step with those three choices switched off agrees to fp32
+    re-association."""
+    from gat_amd import GATConv, _lib, synth
+    n, f, h, c = 1000000, 25, 8, 30
+    ei = synth.out_degree_k_graph(n, 5, seed=1, device=cuda)
+    torch.manual_seed(0)
+    conv = GATConv(f, c, heads=h, dropout=0.0, input_aggregation=True).to(cuda).eval()
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.rand(1, f, device=cuda).expand(n, f).contiguous()
+    with torch.no_grad():
+        out = conv(x, ei)
+        expect = x[:1] @ conv.lin.weight.t() + conv.bias
+    assert float((out - expect).abs().max()) <= 2e-5 * float(expect.abs().max())
+    xr = torch.rand(n, f, device=cuda)
+    g1 = torch.randn(n, h * c, device=cuda)
+    g2 = torch.randn(n, h * c, device=cuda)
+
+    def step(go):
+        conv.zero_grad()
+        o = conv(xr, ei)
+        o.backward(go)
+        return o.detach(), [p.grad.clone() for p in (conv.lin.weight, conv.att_src, conv.att_dst, conv.bias)]
+
+    _, a = step(g1)
+    _, b = step(g2)
+    o1, t = step(g1 + 2 * g2)
+    for u, v, w in zip(a, b, t):
+        assert float((u + 2 * v - w).abs().max()) <= 3e-5 * float(w.abs().max())
+    for name in ("GATMI_GROUPROWS", "GATMI_QGROUP", "GATMI_OUTGROUP"):
+        _lib.set_option(name, 0)
+    try:
+        o2, t2 = step(g1 + 2 * g2)
+    finally:
+        for name in ("GATMI_GROUPROWS", "GATMI_QGROUP", "GATMI_OUTGROUP"):
+            _lib.set_option(name, -1)
+    assert float((o1 - o2).abs().max()) <= 2e-5 * float(o1.abs().max())
+    for name, u, v in zip(("weight", "att_src", "att_dst", "bias"), t, t2):
+        # a logit within rounding of zero may take the other LeakyReLU slope (DESIGN.md section 6)
+        assert float((u - v).abs().max()) <= 2e-3 * float(v.abs().max()), name
