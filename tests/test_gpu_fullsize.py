@@ -168,3 +168,43 @@ def test_runpy_shaped_million_nodes(cuda):
     for name, u, v in zip(("weight", "att_src", "att_dst", "bias"), t, t2):
         # a logit within rounding of zero may take the other LeakyReLU slope
         assert float((u - v).abs().max()) <= 2e-3 * float(v.abs().max()), name
+
+
+def test_eight_heads_wide_rows_at_scale(cuda):
+    """128 -> 8x32 on 200 k nodes / 5 M power-law edges (hub rows cut into segments): the
+    multi-edge kernels for 5..8 heads (two edges per wave instruction at this row length) --
+    constant rows, linearity of the parameter gradients, agreement with the one-edge kernels."""
+    from gat_amd import GATConv, _lib, synth
+    n, e, f, h, c = 200000, 5000000, 128, 8, 32
+    ei = synth.powerlaw_graph(n, e, 3000, seed=2, device=cuda)
+    torch.manual_seed(1)
+    conv = GATConv(f, c, heads=h, dropout=0.0, input_aggregation=True, stream=False).to(cuda).eval()
+    with torch.no_grad():
+        conv.bias.normal_()
+        x = torch.randn(1, f, device=cuda).expand(n, f).contiguous()
+        out = conv(x, ei)
+        expect = x[:1] @ conv.lin.weight.t() + conv.bias
+    assert float((out - expect).abs().max()) <= 2e-5 * float(expect.abs().max())
+    xr = torch.randn(n, f, device=cuda)
+    g1 = torch.randn(n, h * c, device=cuda)
+    g2 = torch.randn(n, h * c, device=cuda)
+
+    def step(go):
+        conv.zero_grad()
+        o = conv(xr, ei)
+        o.backward(go)
+        return o.detach(), [p.grad.clone() for p in (conv.lin.weight, conv.att_src, conv.att_dst, conv.bias)]
+
+    _, a = step(g1)
+    _, b = step(g2)
+    o1, t = step(g1 + 2 * g2)
+    for u, v, w in zip(a, b, t):
+        assert float((u + 2 * v - w).abs().max()) <= 3e-5 * float(w.abs().max())
+    _lib.set_option("GATMI_EDGE8", 0)
+    try:
+        o2, t2 = step(g1 + 2 * g2)
+    finally:
+        _lib.set_option("GATMI_EDGE8", -1)
+    assert float((o1 - o2).abs().max()) <= 3e-5 * float(o1.abs().max())
+    for name, u, v in zip(("weight", "att_src", "att_dst", "bias"), t, t2):
+        assert float((u - v).abs().max()) <= 2e-3 * float(v.abs().max()), name
