@@ -82,6 +82,8 @@ SYMBOLS = {
     "gatmi_attn_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_attn_fwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_attn_fwd_static": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "gatmi_dropout_mask": (C.c_int, [C.POINTER(Graph), C.c_int, C.c_float, C.c_uint64, C.c_void_p,
                                      C.c_void_p]),
     "gatmi_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),

@@ -11,6 +11,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace gatmi {
 
 struct RowArgs {
@@ -774,18 +776,11 @@ extern "C" size_t gatmi_attn_fwd_workspace_bytes(const gatmi_graph *g, const gat
     return align_up(slots * s->heads * 4) * 2 + align_up(slots * geo.Dp * 4) + 256;
 }
 
-extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *out, float *lse,
-                              void *ws, size_t ws_bytes, void *stream) {
-    if (int e = check_attn(g, a)) return e;
-    Geometry geo;
-    if (int e = make_geometry(a->shape, &geo)) return e;
-    GATMI_REQUIRE(out, "null out");
-    if (ws_bytes < gatmi_attn_fwd_workspace_bytes(g, &a->shape)) {
-        set_error("attn_fwd workspace too small: %zu < %zu", ws_bytes,
-                  gatmi_attn_fwd_workspace_bytes(g, &a->shape));
-        return GATMI_ERR_WS;
-    }
-    hipStream_t st = static_cast<hipStream_t>(stream);
+// Body shared by gatmi_attn_fwd (workspace from the caller) and gatmi_attn_fwd_static (workspace
+// in this library's own device array): arguments are already checked, `ws` holds at least
+// gatmi_attn_fwd_workspace_bytes(g, &a->shape).
+static int attn_fwd_run(const gatmi_graph *g, const gatmi_attn *a, const Geometry &geo, float *out,
+                        float *lse, void *ws, hipStream_t st) {
     RowArgs A;
     fill_common(A, *a, geo);
     A.rowptr = g->rowptr;
@@ -815,6 +810,71 @@ extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *
         GATMI_HIP(hipGetLastError());
     }
     return GATMI_OK;
+}
+
+extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *out, float *lse,
+                              void *ws, size_t ws_bytes, void *stream) {
+    if (int e = check_attn(g, a)) return e;
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    GATMI_REQUIRE(out, "null out");
+    if (ws_bytes < gatmi_attn_fwd_workspace_bytes(g, &a->shape)) {
+        set_error("attn_fwd workspace too small: %zu < %zu", ws_bytes,
+                  gatmi_attn_fwd_workspace_bytes(g, &a->shape));
+        return GATMI_ERR_WS;
+    }
+    return attn_fwd_run(g, a, geo, out, lse, ws, static_cast<hipStream_t>(stream));
+}
+
+// ---- The forward for callers that cannot allocate (HIP graph capture, serving loops): the
+// partial (m, s, acc) triples of cut rows -- the only scratch the forward uses -- live in a
+// device array of this library instead of a caller's workspace.  Every GPU the library runs on
+// holds its own copy of the array at its own address; `scratch` below is only the host-side
+// handle of the symbol, the address kernels may use comes from hipGetSymbolAddress, once per
+// device, and is kept in g_scratch_ptr.
+static __device__ __align__(256) unsigned char scratch[GATMI_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxDevices] = {};
+
+int static_scratch(void **ptr) {
+    int dev = -1;
+    GATMI_HIP(hipGetDevice(&dev));
+    GATMI_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside [0, %d)", dev,
+                  kMaxDevices);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        GATMI_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        GATMI_REQUIRE(p && ((uintptr_t)p & 255) == 0, "static scratch of device %d at %p", dev, p);
+        g_scratch_ptr[dev] = p;
+    }
+    *ptr = g_scratch_ptr[dev];
+    return GATMI_OK;
+}
+}  // namespace
+
+extern "C" int gatmi_attn_fwd_static(const gatmi_graph *g, const gatmi_attn *a, float *out,
+                                     float *lse, void *stream) {
+    if (int e = check_attn(g, a)) return e;
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    GATMI_REQUIRE(out, "null out");
+    const size_t need = gatmi_attn_fwd_workspace_bytes(g, &a->shape);
+    if (need > (size_t)GATMI_STATIC_SCRATCH_BYTES) {
+        set_error("gatmi_attn_fwd_static: %d cut-row segments of %d floats need %zu bytes of "
+                  "scratch, the static array holds %zu; use gatmi_attn_fwd with a workspace or a "
+                  "larger seg_len", g->plan.n_slots, geo.Dp + 2 * a->shape.heads, need,
+                  (size_t)GATMI_STATIC_SCRATCH_BYTES);
+        return GATMI_ERR_WS;
+    }
+    void *ws = nullptr;
+    if (int e = static_scratch(&ws)) return e;
+    // nothing in the scratch has to start at zero: every slot the merge reads is written by the
+    // segment that owns it in the same call
+    return attn_fwd_run(g, a, geo, out, lse, ws, static_cast<hipStream_t>(stream));
 }
 
 namespace {

@@ -43,16 +43,19 @@ extern "C" {
 const char *gatmi_last_error(void);
 int gatmi_version(void);
 
+/* Kernel-selection switch for A/B runs and for the parity tests of the fallback kernels
+ * (no counterpart in the reference).  name = one of GATMI_STREAM, GATMI_FWD3, GATMI_BWD3,
+ * GATMI_BWD2, GATMI_EDGE8, GATMI_GROUPROWS, GATMI_GEMM_V2, GATMI_QGROUP, GATMI_OUTGROUP,
+ * GATMI_KRES, GATMI_KREG, GATMI_KREG_TAIL, GATMI_KREG_WIDE, GATMI_DW_STREAM, GATMI_DW_TAIL
+ * (what each selects: DESIGN.md section 5, "A/B switches"); value >= 0 sets it, value < 0 hands
+ * the decision back to the environment variable of the same name. */
+int gatmi_set_option(const char *name, int value);
+
 /* Per-kernel timing for benchmarks (no counterpart in the reference, which only prints
  * epoch wall time at model.py:89,105): while enabled, every kernel the library launches
  * is bracketed by HIP events on its launch stream.  gatmi_prof_read waits for the
  * recorded events, copies up to max_records (tag[32], milliseconds) pairs out (host
  * pointers), clears the list and returns the number copied. */
-/* Kernel-selection switch for A/B runs and for the parity tests of the fallback kernels
- * (no counterpart in the reference): name = GATMI_STREAM, GATMI_BWD2, GATMI_KRES, GATMI_KREG,
- * GATMI_KREG_TAIL, GATMI_DW_STREAM, GATMI_DW_TAIL; value 0/1, or < 0 to
- * hand the decision back to the environment variable of the same name. */
-int gatmi_set_option(const char *name, int value);
 int gatmi_prof_enable(int on);
 int gatmi_prof_read(char *tags /* host [max_records][32] */, float *ms /* host */,
                     int max_records);
@@ -163,6 +166,19 @@ typedef struct gatmi_attn {
 size_t gatmi_attn_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
 int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *out, float *lse,
                    void *ws, size_t ws_bytes, void *stream);
+
+/* gatmi_attn_fwd without a workspace argument.  NO COUNTERPART IN THE REFERENCE: it is for
+ * callers that cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The only scratch the forward uses, the partial
+ * (max, sum, accumulator) triples of destination rows cut into segments, lives in a device
+ * array of the library itself: GATMI_STATIC_SCRATCH_BYTES per GPU the library runs on, held
+ * until the process ends.  Same kernels and bit-identical results as gatmi_attn_fwd; returns
+ * GATMI_ERR_WS when gatmi_attn_fwd_workspace_bytes(g, &a->shape) exceeds the array (about
+ * 7,900 segments of a 4x64 layer).  Calls no hipMalloc / hipFree.  All calls on one GPU share
+ * the array: calls that overlap on one GPU (two streams, two threads) race -- serialise them. */
+#define GATMI_STATIC_SCRATCH_BYTES (8u << 20)
+int gatmi_attn_fwd_static(const gatmi_graph *g, const gatmi_attn *a, float *out, float *lse,
+                          void *stream);
 
 /* The keep-mask GATMI_MASK_HASH derives from (seed, edge, head), written out as bytes
  * [E', H] in dst-CSR order: what F.dropout's Bernoulli draw is to the reference (row a8).
