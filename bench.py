@@ -27,15 +27,20 @@ from gat_amd.synth import kernel_bytes  # noqa: E402  (algorithmic bytes per lau
 
 
 def measured_traffic(workload, kernel):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot
-    collect counters itself); None when no measurement exists for this workload/kernel."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        return t["kernels"].get(kernel) if t.get("workload") == workload else None
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/
+    (bench.py cannot collect counters itself: this is a RECORDED figure of the same command, not
+    one measured in this run) -> (bytes or None, where it came from)."""
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("workload") == workload and t["kernels"].get(kernel) is not None:
+                return t["kernels"][kernel], (f"profiles/{rnd}/pmc_traffic.json: recorded rocprofv3 --pmc "
+                                              "FETCH_SIZE/WRITE_SIZE passes of this command, not measured in this run")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def cpu_baseline(name, seed, budget_s=25.0):
@@ -56,7 +61,7 @@ def cpu_baseline(name, seed, budget_s=25.0):
     ep = ei.size(1) - int((ei[0] == ei[1]).sum()) + n
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(11):            # 1 warm-up + up to 10 timed runs, inside the budget
         t0 = time.time()
         O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
         times.append(time.time() - t0)
@@ -90,6 +95,13 @@ def main():
                          "auto = what GATConv picks (on here: x carries no gradient, F < H*C)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "h", "x", "xs", "as"],
                     help="N>1: what the destination partition all-gathers (gat_amd/dist.py)")
+    ap.add_argument("--partition", default="edges", choices=["edges", "nodes"],
+                    help="N>1: destination ranges of equal in-edge count (SURVEY.md 8e) or equal node count")
+    ap.add_argument("--no-exchange-h", action="store_true",
+                    help="N>1: skip the second timed region (exchange=h, the north_star's all-gather of "
+                         "projected features) that is reported next to --exchange auto")
+    ap.add_argument("--no-extra-layers", action="store_true",
+                    help="N=1: skip the hidden-layer and model-sum measurements (products only)")
     args = ap.parse_args()
     if os.environ.get("GAT_HANG_DUMP"):      # debugging aid: dump every thread's stack and exit
         import faulthandler
@@ -106,8 +118,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from gat_amd import GATConv, _lib, synth
-    from gat_amd.graph import cached_graph
+    from gat_amd import synth
 
     if world > 1:
         import torch.distributed as dist
@@ -119,11 +130,93 @@ def main():
         from gat_amd.dist import bench_partitioned
         return bench_partitioned(args, rank, world, dev)
 
-    ei, n, f, h, c = synth.workload_graph(args.workload, args.seed, dev)
+    head = measure_layer(args.workload, args, dev)
+    n, ep, f, h, c, avg, kb = (head[k] for k in ("nodes", "edges", "f", "h", "c", "avg", "kb"))
+    dom = max(kb, key=lambda k: avg.get(k, 0.0))
+    achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(args.workload, dom)
+    s8d = survey_8d_bytes(n, ep, h, c)
+    path = "input-side aggregation" if "inagg_fwd" in avg else "projected rows"
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom],
+                "algorithmic_bytes_model": "DESIGN.md section 4: what THIS kernel has to move per launch "
+                                           "(fp32 values, int32 indices)",
+                "survey_8d_bytes": s8d,
+                "survey_8d_note": "SURVEY.md 8d prices one layer fwd+bwd of the projected-row algorithm "
+                                  "(every edge gathers a 4*H*C-byte projected row, twice in the backward); "
+                                  + ("this step gathers the 4*Fs-byte input rows instead and never moves "
+                                     "projected rows, so whole-step survey bytes / step time = "
+                                     f"{s8d['total'] / (head['ms_per_step'] * 1e-3) / 1e9:.0f} GB/s is not an HBM rate"
+                                     if path == "input-side aggregation" else
+                                     "this step is that algorithm with the backward's second gather removed: "
+                                     f"whole-step survey bytes / step time = "
+                                     f"{s8d['total'] / (head['ms_per_step'] * 1e-3) / 1e9:.0f} GB/s")}
+    res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (head["ms_per_step"] * 1e-3),
+           "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": head["text"], "nodes": n, "edges": ep, "in_features": f, "heads": h,
+                      "channels": c, "parallelism": "single GPU", "path": path,
+                      "graph_layout_build_s": round(head["layout_s"], 4)},
+           "roofline": roofline, "kernels": kernel_table(avg, kb)}
+
+    # "report per layer and summed over the model's layers".  The headline is the
+    # network's INPUT layer (x is data: no d_x, input-side aggregation).  The layers behind it take
+    # the projected-row path and produce d_x; the 3-layer network of SURVEY.md 8 on this graph is
+    # input layer + two same-width hidden layers.
+    hidden_name = args.workload + "_hidden"
+    if not args.no_extra_layers and hidden_name in synth.WORKLOADS:
+        hid = measure_layer(hidden_name, args, dev)
+        hdom = max(hid["kb"], key=lambda k: hid["avg"].get(k, 0.0))
+        hach = hid["kb"][hdom] / (hid["avg"][hdom] * 1e-3) / 1e9
+        res["hidden_layer"] = {
+            "workload": hid["text"], "ms_per_step": round(hid["ms_per_step"], 4),
+            "value": ep / (hid["ms_per_step"] * 1e-3), "unit": "edges/s", "path": "projected rows",
+            "roofline": {"bound": "hbm", "kernel": hdom, "achieved": round(hach, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(hach / HBM_PEAK_GBS, 4),
+                         "avg_ms": round(hid["avg"][hdom], 4), "algorithmic_bytes": hid["kb"][hdom],
+                         "survey_8d_bytes": survey_8d_bytes(n, ep, hid["h"], hid["c"])},
+            "kernels": kernel_table(hid["avg"], hid["kb"])}
+        total_ms = head["ms_per_step"] + 2 * hid["ms_per_step"]
+        res["model_sum"] = {
+            "layers": [f"{f}->{h}x{c} (input, no d_x)", f"{hid['f']}->{hid['h']}x{hid['c']} (hidden, d_x)",
+                       f"{hid['f']}->{hid['h']}x{hid['c']} (hidden, d_x; timed once, counted twice)"],
+            "ms_per_step": round(total_ms, 4), "edges_per_s_per_layer": 3 * ep / (total_ms * 1e-3),
+            "note": "sum of the per-layer fwd+bwd times above; value = 3 E' / that sum"}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
+    print(json.dumps(res))
+
+
+def kernel_table(avg, kb):
+    return {k: {"avg_ms": round(v, 4),
+                **({"alg_GBps": round(kb[k] / (v * 1e-3) / 1e9, 1)} if k in kb else {})}
+            for k, v in sorted(avg.items())}
+
+
+def survey_8d_bytes(n, ep, h, c):
+    """SURVEY.md 8d's B_fwd / B_bwd / B_alg for one layer (projected-row algorithm, D = H*C)."""
+    d = h * c
+    fwd = ep * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4)
+    bwd = ep * (8 * d + 16 * h + 12) + n * (8 * d + 16 * h)
+    return {"fwd": fwd, "bwd": bwd, "total": fwd + bwd}
+
+
+def measure_layer(workload, args, dev):
+    """Time `args.steps` forward+backward steps of one GAT layer on the named synthetic graph
+    (inputs resident in HBM, layout built beforehand) and collect the library's per-kernel HIP-event
+    timings over the same steps."""
+    import gc
+
+    from gat_amd import GATConv, _lib, synth
+    from gat_amd.graph import cached_graph
+    ei, n, f, h, c = synth.workload_graph(workload, args.seed, dev)
     d = h * c
     g = torch.Generator(device=dev).manual_seed(args.seed)
     x = torch.randn(n, f, generator=g, device=dev)
-    hidden = args.workload.endswith("_hidden")   # a hidden layer: x has a gradient, d_x is part of the step
+    hidden = workload.endswith("_hidden")   # a hidden layer: x has a gradient, d_x is part of the step
     x.requires_grad_(hidden)
     torch.manual_seed(args.seed)
     conv = GATConv(f, c, heads=h, dropout=args.dropout,
@@ -155,40 +248,21 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
-    recs = _lib.prof_read()
-
     per = {}
-    for tag, ms in recs:
+    for tag, ms in _lib.prof_read():
         per.setdefault(tag, []).append(ms)
     avg = {k: sum(v) / len(v) for k, v in per.items()}
-    kb = kernel_bytes(n, ep, h, d, f)
-    dom = max(kb, key=lambda k: avg.get(k, 0.0))
-    achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(args.workload, dom),
-                "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom]}
-    kernels = {k: {"avg_ms": round(v, 4),
-                   **({"alg_GBps": round(kb[k] / (v * 1e-3) / 1e9, 1)} if k in kb else {})}
-               for k, v in sorted(avg.items())}
-
-    ms_step = elapsed / args.steps * 1e3
-    res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
-           "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
-                                  f"{ei.size(1)} edges ({ep} after self-loop normalisation), "
-                                  f"one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
-                                  f"attention dropout {args.dropout} (train mode)",
-                      "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
-                      "parallelism": "single GPU",
-                      "path": "input-side aggregation" if "inagg_fwd" in avg else "projected rows",
-                      "graph_layout_build_s": round(t_layout, 4)},
-           "roofline": roofline, "kernels": kernels}
-    if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
-    print(json.dumps(res))
+    text = (f"{workload}-shaped synthetic graph: {n} nodes, {ei.size(1)} edges ({ep} after self-loop "
+            f"normalisation), one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
+            f"attention dropout {args.dropout} (train mode)")
+    res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, kb=kernel_bytes(n, ep, h, d, f),
+               ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text)
+    del conv, x, go, layout, ei
+    from gat_amd.graph import clear_graph_cache
+    clear_graph_cache()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

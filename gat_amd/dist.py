@@ -24,17 +24,22 @@ needs no exchange at all besides the parameter all-reduce.
                  x tensor and kept; every step all-gathers only the projected source logits
                  a_src [N, H] (they change with the weights) into the table's last columns
 
-Blocks are equal (B = ceil(N / P) nodes, the last ones shorter or empty) so the
-collectives are the plain equal-shard forms.  The compute steps go through a small backend
+Ranks own contiguous destination ranges holding about the same number of in-edges
+(`balanced_bounds`; `balance="nodes"`: equal blocks of ceil(N / P) nodes).  Shards are padded to
+the longest range so the collectives stay the plain equal-shard forms; gathered tables are
+indexed by padded ids (Partition.to_padded).  The compute steps go through a small backend
 object: `HipBackend` is the product (C ABI, GPU only); tests swap in a CPU stand-in to
 check the partition + collective algebra under gloo.
 """
 from __future__ import annotations
 
 import json
+import os
+import sys
 import time
+import weakref
 from dataclasses import dataclass
-from typing import Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -45,21 +50,43 @@ from . import _lib
 
 @dataclass
 class Partition:
+    """Rank r owns the contiguous destination range [bounds[r], bounds[r+1]).  `bounds` None:
+    equal blocks of ceil(N / P) nodes.  Given (balanced_bounds): ranges of unequal length that
+    hold about the same number of in-edges -- what the per-rank work is proportional to
+    (SURVEY.md 8e).  Either way every collective is the plain equal-shard form: shards are
+    padded to `block` = the longest range, and the gathered tables are indexed by PADDED ids
+    (rank * block + offset inside the rank's range; `to_padded`) -- for equal blocks those are
+    the global ids themselves."""
     num_nodes: int
     world: int
     rank: int
+    bounds: Optional[Tuple[int, ...]] = None
+
+    def __post_init__(self):
+        if self.bounds is not None:
+            b = tuple(int(v) for v in self.bounds)
+            if (len(b) != self.world + 1 or b[0] != 0 or b[-1] != self.num_nodes
+                    or any(b[i] > b[i + 1] for i in range(self.world))):
+                raise ValueError(f"bounds {b} do not split {self.num_nodes} nodes over {self.world} ranks")
+            self.bounds = b
 
     @property
     def block(self) -> int:
-        return (self.num_nodes + self.world - 1) // self.world
+        if self.bounds is None:
+            return (self.num_nodes + self.world - 1) // self.world
+        return max(max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world)), 1)
 
     @property
     def lo(self) -> int:
-        return min(self.rank * self.block, self.num_nodes)
+        if self.bounds is None:
+            return min(self.rank * self.block, self.num_nodes)
+        return self.bounds[self.rank]
 
     @property
     def hi(self) -> int:
-        return min(self.lo + self.block, self.num_nodes)
+        if self.bounds is None:
+            return min(self.lo + self.block, self.num_nodes)
+        return self.bounds[self.rank + 1]
 
     @property
     def n_local(self) -> int:
@@ -69,17 +96,75 @@ class Partition:
     def padded_nodes(self) -> int:
         return self.block * self.world
 
+    @property
+    def plo(self) -> int:
+        """first row of this rank's shard in a gathered (padded) table"""
+        return self.rank * self.block
+
+    @property
+    def phi(self) -> int:
+        return self.plo + self.n_local
+
+    def to_padded(self, ids: Tensor) -> Tensor:
+        """global node ids -> rows of a gathered table"""
+        if self.bounds is None:
+            return ids
+        b = torch.tensor(self.bounds, dtype=ids.dtype, device=ids.device)
+        owner = torch.searchsorted(b, ids, right=True) - 1
+        return owner * self.block + (ids - b[owner])
+
+
+def balanced_bounds(edge_index: Tensor, num_nodes: int, world: int) -> Tuple[int, ...]:
+    """Contiguous destination ranges with about equal in-edge counts (after self-loop
+    normalisation: every node counts its own loop): bounds[r] = the first node at which the
+    prefix sum of in-degrees reaches r / P of the total.  Computed from the whole edge_index,
+    so every rank derives the same bounds without talking to the others."""
+    src, dst = edge_index[0], edge_index[1]
+    deg = torch.bincount(dst[src != dst], minlength=num_nodes) + 1
+    pref = torch.cumsum(deg, 0)
+    total = int(pref[-1]) if num_nodes else 0
+    targets = torch.tensor([total * r // world for r in range(1, world)], dtype=pref.dtype,
+                           device=pref.device)
+    cuts = torch.searchsorted(pref, targets, right=False) + 1 if world > 1 else targets
+    cuts = [min(int(c), num_nodes) for c in cuts.tolist()]
+    bounds = [0] + cuts + [num_nodes]
+    for i in range(1, len(bounds)):                # monotone (hubs can make a target repeat)
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return tuple(bounds)
+
+
+_PARTS: Dict[Tuple, Tuple["weakref.ref", Tuple[int, ...]]] = {}
+
+
+def make_partition(edge_index: Tensor, num_nodes: int, world: int, rank: int,
+                   balance: str = "edges") -> Partition:
+    """The partition every layer of a network (and its caller, who slices x and y) shares:
+    balance = "edges" (balanced_bounds, cached per edge_index object) or "nodes" (equal blocks)."""
+    if balance == "nodes":
+        return Partition(num_nodes, world, rank)
+    if balance != "edges":
+        raise ValueError(f"balance must be 'edges' or 'nodes', got {balance!r}")
+    key = (id(edge_index), edge_index._version, num_nodes, world)
+    hit = _PARTS.get(key)
+    if hit is None or hit[0]() is not edge_index:
+        for k in [k for k, (r, _) in _PARTS.items() if r() is None]:
+            del _PARTS[k]
+        hit = (weakref.ref(edge_index), balanced_bounds(edge_index, num_nodes, world))
+        _PARTS[key] = hit
+    return Partition(num_nodes, world, rank, hit[1])
+
 
 def local_edges(edge_index: Tensor, part: Partition) -> Tensor:
     """This rank's share of the NORMALISED edge list: in-edges of its destinations in their
     original order with self-loops removed, then one loop per own node (exactly what
-    remove_self_loops + add_self_loops leaves for those destinations).  Row 0 keeps global
-    source ids, row 1 becomes local destination ids."""
+    remove_self_loops + add_self_loops leaves for those destinations).  Row 0 holds the
+    sources as rows of the gathered table (padded ids; == global ids for equal blocks), row 1
+    local destination ids."""
     src, dst = edge_index[0], edge_index[1]
     keep = (dst >= part.lo) & (dst < part.hi) & (src != dst)
-    loops = torch.arange(part.lo, part.hi, dtype=edge_index.dtype, device=edge_index.device)
-    return torch.stack([torch.cat([src[keep], loops]),
-                        torch.cat([dst[keep] - part.lo, loops - part.lo])])
+    loops = torch.arange(part.n_local, dtype=edge_index.dtype, device=edge_index.device)
+    return torch.stack([torch.cat([part.to_padded(src[keep]), loops + part.plo]),
+                        torch.cat([dst[keep] - part.lo, loops])])
 
 
 # ------------------------------------------------------------------ collectives
@@ -124,7 +209,7 @@ class HipBackend:
     def build_layout(self, local_ei: Tensor, part: Partition):
         from .graph import build_graph
         return build_graph(local_ei, part.padded_nodes, add_self_loops=False, seg_len=self.seg_len,
-                           num_dst=part.n_local, dst_offset=part.lo)
+                           num_dst=part.n_local, dst_offset=part.plo)
 
     def project_fwd(self, x, w, att_d, cfg):
         from . import ops
@@ -195,7 +280,7 @@ class _PartitionedFn(torch.autograd.Function):
         if exchange == "x":
             x_full = all_gather_rows(_pad_rows(x_local, part.block), part.world, group)
             hp_full, a_dst_full = be.project_fwd(x_full, weight, att_d, cfg)
-            a_dst = a_dst_full[part.lo:part.hi].contiguous()
+            a_dst = a_dst_full[part.plo:part.phi].contiguous()
             x_saved = x_full
         else:
             hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
@@ -217,7 +302,7 @@ class _PartitionedFn(torch.autograd.Function):
             layout, cfg, x_saved.size(1), hp_full, a_dst, att_s, att_d, bias_c, out, lse,
             grad_out.contiguous())
         if exchange == "x":
-            own = d_hp_part[part.lo:part.hi]          # a view: the term lands in d_hp_part
+            own = d_hp_part[part.plo:part.phi]        # a view: the term lands in d_hp_part
             be.add_dst_term(own, d_a_dst, att_d, cfg)
             d_w, d_x_part = be.project_bwd(x_saved, weight, d_hp_part, cfg, need_dx)
             d_x = None
@@ -250,10 +335,18 @@ class _PartitionedInAggFn(torch.autograd.Function):
             table = all_gather_rows(_pad_rows(xs_local, part.block), part.world, group)
         else:
             c0, cn = be.inagg_logit_columns(x_local.size(1), cfg)
-            key = (x_local.data_ptr(), tuple(x_local.shape), x_local._version, part.world)
-            if cache.get("key") != key:       # first call for this x: replicate the rows once
-                cache["key"] = key
+            # The cached table is valid for THIS x tensor object at THIS version only: a pointer
+            # + shape key would also match a new tensor the allocator placed at a freed address
+            # (the per-step dropout output PartitionedGAT feeds conv1), leaving stale x columns
+            # under fresh logits.  A per-step temporary therefore never hits and takes the full
+            # all-gather every step -- the same traffic as exchange="xs".
+            owner = cache.get("owner")
+            hit = (owner is not None and owner() is x_local and cache.get("version") == x_local._version
+                   and cache.get("world") == part.world and cache.get("bounds") == part.bounds)
+            if not hit:                       # first call for this x: replicate the rows once
                 cache["table"] = all_gather_rows(_pad_rows(xs_local, part.block), part.world, group)
+                cache["owner"], cache["version"] = weakref.ref(x_local), x_local._version
+                cache["world"], cache["bounds"] = part.world, part.bounds
             else:                             # later calls: only the logits travel
                 logits = all_gather_rows(_pad_rows(xs_local[:, c0:c0 + cn], part.block),
                                          part.world, group)
@@ -283,9 +376,12 @@ class PartitionedGATConv(nn.Module):
     all-reduced, so every rank steps identically."""
 
     def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, dropout=0.0,
-                 bias=True, backend=None, group=None, exchange="auto"):
+                 bias=True, backend=None, group=None, exchange="auto", balance="edges"):
         super().__init__()
         from .layer import _glorot_
+        if balance not in ("edges", "nodes"):
+            raise ValueError(f"balance must be 'edges' or 'nodes', got {balance!r}")
+        self.balance = balance      # destination ranges of equal in-edge count / equal node count
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.negative_slope, self.dropout = negative_slope, dropout
         self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
@@ -300,19 +396,28 @@ class PartitionedGATConv(nn.Module):
         if exchange not in ("auto", "h", "x", "xs", "as"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
         self.exchange = exchange
-        self._layouts = {}
+        self._layouts = None
         self._table_cache = {}
 
+    def partition_for(self, edge_index: Tensor, num_nodes: int) -> Partition:
+        """This rank's destination range for the graph (the caller slices x, y, grad_out by it)."""
+        return make_partition(edge_index, num_nodes, dist.get_world_size(self.group),
+                              dist.get_rank(self.group), self.balance)
+
     def layout_for(self, edge_index: Tensor, part: Partition):
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, part.rank)
-        if key not in self._layouts:
-            self._layouts = {key: self.backend.build_layout(local_edges(edge_index, part), part)}
-        return self._layouts[key]
+        """The rank's CSR, built once per edge_index OBJECT (weak reference + version: an address
+        reused by another tensor of the same shape does not match)."""
+        owner, version, key, layout = self._layouts or (None, None, None, None)
+        if (owner is None or owner() is not edge_index or version != edge_index._version
+                or key != (part.rank, part.world, part.bounds)):
+            layout = self.backend.build_layout(local_edges(edge_index, part), part)
+            self._layouts = (weakref.ref(edge_index), edge_index._version,
+                             (part.rank, part.world, part.bounds), layout)
+        return layout
 
     def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
         from .ops import AttnConfig
-        world = dist.get_world_size(self.group)
-        part = Partition(num_nodes, world, dist.get_rank(self.group))
+        part = self.partition_for(edge_index, num_nodes)
         if x_local.size(0) != part.n_local:
             raise ValueError(f"rank {part.rank} owns nodes [{part.lo}, {part.hi}) but got "
                              f"{x_local.size(0)} rows of x")
@@ -397,23 +502,41 @@ class PartitionedGAT(nn.Module):
     back-propagates its own rows' share of that mean; call `sync_grads()` before the optimizer
     step (BatchNorm's weight and bias gradients are partial sums until then)."""
 
-    def __init__(self, num_features, num_classes, hidden_dim=16, dropout=0.7, backend=None, group=None):
+    def __init__(self, num_features, num_classes, hidden_dim=16, dropout=0.7, backend=None, group=None,
+                 balance="edges"):
         super().__init__()
-        kw = dict(dropout=dropout, backend=backend, group=group)
+        kw = dict(dropout=dropout, backend=backend, group=group, balance=balance)
         self.conv1 = PartitionedGATConv(num_features, hidden_dim, heads=8, **kw)
         self.bn1 = nn.BatchNorm1d(hidden_dim * 8)
         self.conv2 = PartitionedGATConv(hidden_dim * 8, hidden_dim, heads=8, **kw)
         self.bn2 = nn.BatchNorm1d(hidden_dim * 8)
         self.conv3 = PartitionedGATConv(hidden_dim * 8, num_classes, heads=1, **kw)
         self.p, self.group = dropout, group
+        self._gens = {}
+
+    def partition_for(self, edge_index: Tensor, num_nodes: int) -> Partition:
+        return self.conv1.partition_for(edge_index, num_nodes)
+
+    def _drop(self, t: Tensor) -> Tensor:
+        """Feature dropout (model.py:31,39,42,45) drawn from a generator of this rank's own:
+        ranks are seeded identically so that their parameters agree, and torch's global
+        generator would then hand every rank the same mask pattern for its different rows."""
+        if not self.training or self.p <= 0.0:
+            return t
+        gen = self._gens.get(t.device)
+        if gen is None:
+            gen = torch.Generator(device=t.device)
+            gen.manual_seed(torch.initial_seed() + 7919 * (dist.get_rank(self.group) + 1))
+            self._gens[t.device] = gen
+        keep = torch.rand(t.shape, generator=gen, device=t.device) >= self.p
+        return t * keep.to(t.dtype) / (1.0 - self.p)
 
     def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
-        drop = lambda t: torch.nn.functional.dropout(t, self.p, self.training)
-        x = self.conv1(drop(x_local), edge_index, num_nodes)
-        x = sync_elu_bn_dropout(x, self.bn1, self.p, self.training, num_nodes, self.group)
-        x = self.conv2(x, edge_index, num_nodes)
-        x = sync_elu_bn_dropout(x, self.bn2, self.p, self.training, num_nodes, self.group)
-        return torch.log_softmax(self.conv3(x, edge_index, num_nodes), dim=1)
+        x = self.conv1(self._drop(x_local), edge_index, num_nodes)
+        x = sync_elu_bn_dropout(x, self.bn1, 0.0, self.training, num_nodes, self.group)
+        x = self.conv2(self._drop(x), edge_index, num_nodes)
+        x = sync_elu_bn_dropout(x, self.bn2, 0.0, self.training, num_nodes, self.group)
+        return torch.log_softmax(self.conv3(self._drop(x), edge_index, num_nodes), dim=1)
 
     def loss_share(self, logp_local: Tensor, y_local: Tensor, num_nodes: int) -> Tensor:
         """This rank's share of F.nll_loss(out, y) over all N nodes (model.py:53): the shares of
@@ -441,36 +564,10 @@ EXCHANGE_TEXT = {
 }
 
 
-def bench_partitioned(args, rank: int, world: int, dev) -> None:
-    """One products-shaped layer, destination-partitioned over `world` GPUs; rank 0 prints
-    bench.py's JSON line.  Every rank regenerates the same graph from the seed and keeps
-    its own block."""
-    from . import synth
-    ei, n, f, h, c = synth.workload_graph(args.workload, args.seed, dev)
-    part = Partition(n, world, rank)
-    g = torch.Generator(device=dev).manual_seed(args.seed)
-    x = torch.randn(n, f, generator=g, device=dev)[part.lo:part.hi].contiguous()
-    torch.manual_seed(args.seed)
-    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout,
-                              exchange=getattr(args, "exchange", "auto")).to(dev).train()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    layout = conv.layout_for(ei, part)
-    torch.cuda.synchronize()
-    t_layout = time.time() - t0
-    edges = torch.tensor([layout.num_edges], device=dev, dtype=torch.int64)
-    dist.all_reduce(edges)
-    ep = int(edges.item())
-    go = torch.randn(part.n_local, h * c, generator=g, device=dev)
-    from .ops import AttnConfig
-    mode = conv.resolve_exchange(x, AttnConfig(h, c))
-
-    def step():
-        conv.zero_grad(set_to_none=True)
-        out = conv(x, ei, n)
-        out.backward(go)
-
-    for _ in range(args.warmup):
+def _timed_steps(step, steps, warmup, dev):
+    """bench.py's contract: warm-up, then exactly `steps` steps between barrier + synchronize on
+    both sides, MAX over ranks.  -> (seconds, {kernel tag: mean ms on this rank})"""
+    for _ in range(warmup):
         step()
     _lib.prof_read()
     torch.cuda.synchronize()
@@ -478,7 +575,7 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     torch.cuda.synchronize()
     _lib.prof_enable(True)          # per-kernel HIP events, as in the single-GPU run
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dist.barrier()
@@ -486,11 +583,63 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     _lib.prof_enable(False)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
     per = {}
     for tag, ms in _lib.prof_read():
         per.setdefault(tag, []).append(ms)
-    avg = {k: sum(v) / len(v) for k, v in per.items()}
+    return float(el.item()), {k: sum(v) / len(v) for k, v in per.items()}
+
+
+def bench_partitioned(args, rank: int, world: int, dev) -> None:
+    """One products-shaped layer, destination-partitioned over `world` GPUs; rank 0 prints
+    bench.py's JSON line.  Every rank regenerates the same graph from the seed and keeps
+    its own destination range.  `value` is the mode --exchange names (auto: what the layer picks
+    by itself); the line also carries the north_star's own pattern -- all-gather of the projected
+    features + all-reduce of the weight gradients, exchange="h" -- timed the same way, under
+    "exchange_h"."""
+    from . import synth
+    from .ops import AttnConfig
+    ei, n, f, h, c = synth.workload_graph(args.workload, args.seed, dev)
+    balance = getattr(args, "partition", "edges")
+    part = make_partition(ei, n, world, rank, balance)
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    x = torch.randn(n, f, generator=g, device=dev)[part.lo:part.hi].contiguous()
+    go = torch.randn(n, h * c, generator=g, device=dev)[part.lo:part.hi].contiguous()
+    hidden = args.workload.endswith("_hidden")
+    x.requires_grad_(hidden)
+    torch.manual_seed(args.seed)
+    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout, balance=balance,
+                              exchange=getattr(args, "exchange", "auto")).to(dev).train()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    layout = conv.layout_for(ei, part)
+    torch.cuda.synchronize()
+    t_layout = time.time() - t0
+    # every rank's (edges, nodes): one all-reduce of a [world, 2] table with the own row filled in.
+    # It is also the first collective of the process and runs on the main thread -- communicator
+    # set-up must not happen inside the backward (autograd's thread), where the first all-reduce
+    # of a gloo rehearsal was seen to hang.
+    shares = torch.zeros(world, 2, device=dev, dtype=torch.int64)
+    shares[rank, 0], shares[rank, 1] = layout.num_edges, part.n_local
+    dist.all_reduce(shares)
+    shares = shares.tolist()
+    ep = int(sum(s[0] for s in shares))
+    mode = conv.resolve_exchange(x, AttnConfig(h, c))
+
+    trace = bool(os.environ.get("GAT_TRACE"))
+
+    def step():
+        conv.zero_grad(set_to_none=True)
+        x.grad = None
+        out = conv(x, ei, n)
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] {time.time() % 1000:.2f} forward done", file=sys.stderr, flush=True)
+        out.backward(go)
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] {time.time() % 1000:.2f} backward done", file=sys.stderr, flush=True)
+
+    elapsed, avg = _timed_steps(step, args.steps, args.warmup, dev)
     # roofline of rank 0's dominant kernel on ITS share: local destination rows, local edges
     kb = synth.kernel_bytes(part.n_local, layout.num_edges, h, h * c, f)
     roofline = None
@@ -501,6 +650,14 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
                     "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom],
                     "scope": f"rank 0 of {world}: {part.n_local} destination rows, {layout.num_edges} edges"}
+    other = None
+    if mode != "h" and not getattr(args, "no_exchange_h", False):
+        conv.exchange = "h"
+        conv._table_cache.clear()
+        el_h, avg_h = _timed_steps(step, args.steps, args.warmup, dev)
+        other = {"ms_per_step": round(el_h / args.steps * 1e3, 4), "value": ep / (el_h / args.steps),
+                 "unit": "edges/s", "parallelism": EXCHANGE_TEXT["h"],
+                 "kernels": {k: {"avg_ms": round(v, 4)} for k, v in sorted(avg_h.items())}}
     if rank == 0:
         res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
                "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -508,13 +665,19 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
                                       f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
-                                      f"layer {f}->{h}x{c}, attention dropout {args.dropout} (train mode)",
+                                      f"layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
+                                      f"attention dropout {args.dropout} (train mode)",
                           "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
-                          "parallelism": f"destination partition x{world}, exchange={mode}: "
-                                         + EXCHANGE_TEXT[mode] + f", {dist.get_backend()}",
+                          "parallelism": f"destination partition x{world} (ranges balanced by "
+                                         f"{'in-edge' if balance == 'edges' else 'node'} count), "
+                                         f"exchange={mode}: " + EXCHANGE_TEXT[mode] + f", {dist.get_backend()}",
+                          "partition": {"balance": balance,
+                                        "edges_per_rank": [int(s[0]) for s in shares],
+                                        "nodes_per_rank": [int(s[1]) for s in shares]},
                           "graph_layout_build_s": round(t_layout, 4)},
                "roofline": roofline,
                "kernels": {k: {"avg_ms": round(v, 4)} for k, v in sorted(avg.items())},
+               "exchange_h": other,
                "cpu_baseline": None}
         print(json.dumps(res))
     dist.destroy_process_group()

@@ -18,3 +18,15 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """fp32 parity actually achieved by this session's GPU comparisons (tests/parity_log.py)."""
+    try:
+        import parity_log
+    except ImportError:
+        return
+    if parity_log.RECORDS:
+        for line in parity_log.summary_lines():
+            terminalreporter.write_line(line)
+        parity_log.dump(ROOT)

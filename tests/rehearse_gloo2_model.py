@@ -18,7 +18,7 @@ def worker(rank, world, port, q):
     try:
         import cases
         from oracle import gat_oracle as O
-        from gat_amd.dist import Partition, PartitionedGAT
+        from gat_amd.dist import PartitionedGAT
         dev = torch.device("cuda:0")
         ei, n = cases.knn_graph(n=3000, f=25, seed=2)
         g = torch.Generator().manual_seed(3)
@@ -28,11 +28,12 @@ def worker(rank, world, port, q):
         ref = O.OracleGAT(25, 2, hidden_dim=30, dropout=0.0)
         model = PartitionedGAT(25, 2, hidden_dim=30, dropout=0.0).to(dev)
         model.load_state_dict(ref.state_dict())
-        part = Partition(n, world, rank)
         ref.train(); ref_logp = ref(x, ei); ref_loss = torch.nn.functional.nll_loss(ref_logp, y); ref_loss.backward()
         model.train()
+        eid = ei.to(dev)
+        part = model.partition_for(eid, n)
         # gloo moves CPU tensors: collectives on CUDA tensors go through gloo's device copy path
-        logp = model(x[part.lo:part.hi].to(dev), ei.to(dev), n)
+        logp = model(x[part.lo:part.hi].to(dev), eid, n)
         share = model.loss_share(logp, y[part.lo:part.hi].to(dev), n)
         share.backward(); model.sync_grads()
         err = float((logp.detach().cpu() - ref_logp.detach()[part.lo:part.hi]).abs().max())

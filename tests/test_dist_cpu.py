@@ -49,7 +49,7 @@ class OracleBackend:
             o = self._out(layout, cfg, leaves[0], leaves[1], leaves[2], leaves[3])
             o.backward(grad_out)
         d_a_dst = leaves[1].grad
-        h_loc = hp_full[part.lo:part.hi].view(-1, cfg.heads, cfg.channels)
+        h_loc = hp_full[part.plo:part.phi].view(-1, cfg.heads, cfg.channels)
         d_att_dst = (d_a_dst.unsqueeze(-1) * h_loc).sum(0).reshape(-1)
         return leaves[0].grad, leaves[2].grad, d_att_dst, leaves[3].grad, d_a_dst
 
@@ -99,32 +99,39 @@ class OracleBackend:
         with torch.enable_grad():   # logits recomputed from the leaves so that d_W sees them
             hh = (x_full @ wl.t()).view(-1, h_, c_)
             a_src = (hh * asl.view(1, h_, c_)).sum(-1)
-            a_d = (hh[part.lo:part.hi] * adl.view(1, h_, c_)).sum(-1)
+            a_d = (hh[part.plo:part.phi] * adl.view(1, h_, c_)).sum(-1)
             self._inagg_out(layout, cfg, x_full, a_src, a_d, wl, bl).backward(grad_out)
         return wl.grad, asl.grad, adl.grad, bl.grad
 
 
-def _worker(rank, world, port, n, gname, exchange, q):
+def _worker(rank, world, port, n, gname, exchange, balance, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gat_amd.dist import Partition, PartitionedGATConv
+        from gat_amd.dist import PartitionedGATConv
         torch.set_num_threads(1)
         ei, n_ = cases.GRAPHS[gname]() if n is None else cases.random_multigraph(n=n, e=6 * n)
         f, h, c = 6, 3, 5
         x, w, a_s, a_d, b, go = [t.double() for t in cases.layer_inputs(n_, f, h, c)]
-        part = Partition(n_, world, rank)
-        conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend(), exchange=exchange).double().eval()
+        conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend(), exchange=exchange,
+                                  balance=balance).double().eval()
+        part = conv.partition_for(ei, n_)
+        if balance == "edges" and gname == "star":      # the hub's range is much shorter than the rest
+            assert part.bounds is not None and part.bounds[1] < n_ // world
         with torch.no_grad():
             conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
         inagg = exchange in ("xs", "as")
         xl = x[part.lo:part.hi].clone().requires_grad_(not inagg)
-        steps = 2 if exchange == "as" else 1     # second step: cached rows, fresh logits
+        steps = 3 if exchange == "as" else 1     # second step: cached rows, fresh logits
         for step in range(steps):
             conv.zero_grad()
             if step == 1:                         # the weights moved: a_src must be re-gathered
                 with torch.no_grad():
                     w = w * 1.25; conv.lin.weight.copy_(w)
+            if step == 2:                         # ANOTHER x of the same shape, most likely at the
+                x = x.flip(0) * 0.5               # address just freed: the cached rows are stale
+                del xl
+                xl = x[part.lo:part.hi].clone()
             out = conv(xl, ei, n_)
             out.backward(go[part.lo:part.hi])
         ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
@@ -144,10 +151,11 @@ def _worker(rank, world, port, n, gname, exchange, q):
         dist.destroy_process_group()
 
 
-def _run(world, n, gname, exchange, port):
+def _run(world, n, gname, exchange, port, balance="nodes"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gname, exchange, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gname, exchange, balance, q))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -166,24 +174,81 @@ def test_partitioned_layer_equals_single_process(world, n, gname, exchange, port
     _run(world, n, gname, exchange, port)
 
 
-def test_local_edges_keep_reference_order():
-    from gat_amd.dist import Partition, local_edges
+@pytest.mark.parametrize("world,n,gname,exchange,port", [
+    (2, None, "star", "h", 29641), (3, None, "star", "as", 29642), (2, 50, None, "x", 29643),
+    (3, 50, None, "xs", 29644), (3, None, "hub_source", "h", 29645), (4, 9, None, "as", 29646)])
+def test_partitioned_layer_with_edge_balanced_ranges(world, n, gname, exchange, port):
+    """Destination ranges of equal in-edge count -- unequal node counts, shards
+    padded to the longest, sources renumbered into the padded table: same results."""
+    _run(world, n, gname, exchange, port, balance="edges")
+
+
+def test_balanced_bounds_split_the_in_edges_evenly():
+    from gat_amd import synth
+    from gat_amd.dist import Partition, balanced_bounds, local_edges, make_partition
+    n, e, world = 20000, 300000, 8
+    ei = synth.powerlaw_graph(n, e, 4000, seed=3)
+    # hubs at the low ids (a real graph ordered by degree): equal node blocks are badly skewed
+    order = torch.argsort(torch.bincount(ei[1], minlength=n), descending=True)
+    rank_of = torch.empty_like(order); rank_of[order] = torch.arange(n)
+    ei = rank_of[ei]
+    bounds = balanced_bounds(ei, n, world)
+    assert bounds[0] == 0 and bounds[-1] == n and list(bounds) == sorted(bounds)
+    per_edges = [local_edges(ei, Partition(n, world, r, bounds)).size(1) for r in range(world)]
+    per_nodes = [local_edges(ei, Partition(n, world, r)).size(1) for r in range(world)]
+    total = sum(per_edges)
+    assert total == sum(per_nodes) == O.build_csr(ei, n).num_edges
+    assert max(per_edges) <= 1.05 * total / world + 4000      # within 5 % + one hub row
+    assert max(per_nodes) > 2 * total / world                 # what equal blocks would have given
+    # padded ids: a bijection of the nodes into [0, world * block), rank-major
+    part = make_partition(ei, n, world, 3)
+    assert part.bounds == bounds
+    pid = part.to_padded(torch.arange(n))
+    assert pid.unique().numel() == n and int(pid.max()) < part.padded_nodes
+    for r in range(world):
+        pr = Partition(n, world, r, bounds)
+        assert torch.equal(pid[pr.lo:pr.hi], torch.arange(pr.plo, pr.phi))
+
+
+def test_exchange_mode_resolved_for_every_bench_workload():
+    """What `exchange="auto"` picks for each synth.WORKLOADS entry (bench.py --gpus N): the input
+    layers take the input-side path with only a_src on the wire ("as"); layers whose input is wider
+    than the output (Cora-shaped) or carries a gradient (the hidden layers) all-gather h."""
+    from gat_amd import ops, synth
+    from gat_amd.dist import PartitionedGATConv
+    want = {"cora": "h", "cora_uniform": "h", "arxiv": "as", "arxiv_uniform": "as", "products": "as",
+            "products_uniform": "as", "runpy10k": "as", "runpy100k": "as", "runpy1m": "as",
+            "arxiv_hidden": "h", "products_hidden": "h"}
+    assert set(want) == set(synth.WORKLOADS)
+    for name, (n, e, f, h, c, _) in synth.WORKLOADS.items():
+        conv = PartitionedGATConv(f, c, heads=h)
+        x = torch.zeros(4, f, requires_grad=name.endswith("_hidden"))
+        assert conv.resolve_exchange(x, ops.AttnConfig(h, c)) == want[name], name
+        if want[name] == "h":                                  # forcing the input-side modes raises
+            conv.exchange = "as"
+            with pytest.raises(RuntimeError, match="exchange='as'"):
+                conv.resolve_exchange(x, ops.AttnConfig(h, c))
+
+
+@pytest.mark.parametrize("balance", ["nodes", "edges"])
+def test_local_edges_keep_reference_order(balance):
+    from gat_amd.dist import local_edges, make_partition
     ei, n = cases.random_multigraph()
     norm = O.normalize_edges(ei, n)
     for rank in range(3):
-        part = Partition(n, 3, rank)
+        part = make_partition(ei, n, 3, rank, balance)
         loc = local_edges(ei, part)
         sel = (norm[1] >= part.lo) & (norm[1] < part.hi)
-        assert torch.equal(loc[0], norm[0][sel])
+        assert torch.equal(loc[0], part.to_padded(norm[0][sel]))
         assert torch.equal(loc[1] + part.lo, norm[1][sel])
-    assert sum(Partition(n, 3, r).n_local for r in range(3)) == n
+    assert sum(make_partition(ei, n, 3, r, balance).n_local for r in range(3)) == n
 
 
 def _model_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gat_amd.dist import Partition, PartitionedGAT
+        from gat_amd.dist import PartitionedGAT
         torch.set_num_threads(1)
         ei, n = cases.random_multigraph(n=61, e=400)
         g = torch.Generator().manual_seed(11)
@@ -197,7 +262,7 @@ def _model_worker(rank, world, port, q):
                     p.add_(torch.randn(p.shape, generator=g, dtype=torch.float64) * 0.3)
         model = PartitionedGAT(9, 3, hidden_dim=4, dropout=0.0, backend=OracleBackend()).double()
         model.load_state_dict(ref.state_dict())
-        part = Partition(n, world, rank)
+        part = model.partition_for(ei, n)
         for step in range(2):        # second step: running statistics carried over
             ref.train(); ref.zero_grad()
             ref_logp = ref(x, ei)
@@ -236,6 +301,79 @@ def test_partitioned_network_equals_single_process(world, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_model_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _dropout_model_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        from gat_amd.dist import PartitionedGAT, make_partition
+        torch.set_num_threads(1)
+        torch.manual_seed(1234)                # the same on every rank, as a launcher would seed them
+        p = 0.5
+        ei, n = cases.random_multigraph(n=61, e=400)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(n, 9, generator=g, dtype=torch.float64)
+        y = torch.randint(0, 3, (n,), generator=g)
+        ref = O.OracleGAT(9, 3, hidden_dim=4, dropout=0.0).double()     # feature dropout by hand below
+        model = PartitionedGAT(9, 3, hidden_dim=4, dropout=p, backend=OracleBackend()).double()
+        model.load_state_dict(ref.state_dict())
+        part = model.partition_for(ei, n)
+        parts = [make_partition(ei, n, world, r) for r in range(world)]
+        # every rank draws its masks from a generator of its own: replay all of them
+        gens = [torch.Generator().manual_seed(torch.initial_seed() + 7919 * (r + 1)) for r in range(world)]
+        for step in range(3):
+            masks = [torch.cat([torch.rand((parts[r].n_local, cols), generator=gens[r]) >= p
+                                for r in range(world)]) for cols in (9, 32, 32)]
+            assert not torch.equal(masks[0][:parts[0].n_local][:5], masks[0][parts[1].lo:][:5])
+            drop = lambda t, m: t * m.double() / (1.0 - p)
+            ref.train(); ref.zero_grad()
+            h1 = ref.bn1(F.elu(ref.conv1(drop(x, masks[0]), ei)))
+            h2 = ref.bn2(F.elu(ref.conv2(drop(h1, masks[1]), ei)))
+            ref_logp = F.log_softmax(ref.conv3(drop(h2, masks[2]), ei), dim=1)
+            ref_loss = F.nll_loss(ref_logp, y)
+            ref_loss.backward()
+            model.train(); model.zero_grad()
+            # conv1's input is a fresh dropout output every step (exchange "as": its cached
+            # source table must not survive from the step before)
+            logp = model(x[part.lo:part.hi], ei, n)
+            share = model.loss_share(logp, y[part.lo:part.hi], n)
+            share.backward()
+            model.sync_grads()
+            tol = dict(rtol=1e-8, atol=1e-10)
+            torch.testing.assert_close(logp.detach(), ref_logp.detach()[part.lo:part.hi], **tol)
+            torch.testing.assert_close(model.global_loss(share), ref_loss.detach(), **tol)
+            rp = dict(ref.named_parameters())
+            for name, prm in model.named_parameters():
+                torch.testing.assert_close(prm.grad, rp[name].grad, **tol,
+                                           msg=lambda m, name=name: f"step {step} {name}: {m}")
+            with torch.no_grad():               # a plain SGD step on both, so the steps differ
+                for name, prm in model.named_parameters():
+                    prm.sub_(0.1 * prm.grad); rp[name].sub_(0.1 * rp[name].grad)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29651), (3, 29652)])
+def test_partitioned_network_with_feature_dropout(world, port):
+    """Three training steps with feature dropout 0.5: every rank draws its own masks (replayed
+    here from the ranks' generator seeds), conv1's input is a new tensor each step -- the oracle
+    network fed the same masks gives the same log-probabilities, loss and gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dropout_model_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import cases
+import parity_log
 from oracle import gat_oracle as O
 from oracle.csr_ref import build_csr_c
 
@@ -24,13 +25,19 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.n
 
 
 def close(got, ref, name="", floor=0.0):
-    """rtol 1e-5, atol 1e-5 x the reference tensor's largest magnitude.  `floor` is a lower
-    bound for that magnitude, used for gradients that are sums of cancelling terms (on a
-    graph with only self-loops d_att_* is exactly 0 in exact arithmetic): there the noise is
-    measured against the size of one summand, |grad_out| * |h|."""
+    """The bar: |got - ref| <= rtol * |ref| + atol element by element, rtol = 1e-5 and
+    atol = 1e-5 x the reference tensor's largest magnitude -- i.e. a MAX-NORM bound (1e-5 of the
+    tensor's scale) with the element-wise term on top; elements much smaller than the tensor's
+    largest are not held to a relative 1e-5 of their own size.  `floor` is a lower bound for that
+    magnitude, used for gradients that are sums of cancelling terms (on a graph with only
+    self-loops d_att_* is exactly 0 in exact arithmetic): there the noise is measured against the
+    size of one summand, |grad_out| * |h|.  What was actually achieved, max-norm and element by
+    element, is logged per call (tests/parity_log.py) and summarised at the end of the session."""
     got = got.detach().cpu()
     ref = ref.detach().cpu().view_as(got)
-    atol = RTOL * max(float(ref.abs().max()), floor, 1e-30)
+    scale = max(float(ref.abs().max()), floor, 1e-30)
+    atol = RTOL * scale
+    parity_log.record(name, got, ref, scale)
     torch.testing.assert_close(got, ref, rtol=RTOL, atol=atol, msg=lambda m: f"{name}: {m}")
 
 
@@ -671,13 +678,14 @@ def test_properties_at_scale(cuda):
 
 
 # ------------------------------------------------------------------ destination partition (one GPU plays every rank)
+@pytest.mark.parametrize("balance", ["nodes", "edges"])
 @pytest.mark.parametrize("gname,sname,world", [("multigraph", "conv1_h30", 2), ("star", "arxiv_h64", 3),
                                                ("hub_source", "three_heads", 2), ("knn", "cora_l2", 4)])
-def test_partition_kernels_match_oracle(cuda, gname, sname, world):
+def test_partition_kernels_match_oracle(cuda, gname, sname, world, balance):
     """The rectangular (num_dst < num_src) mode the multi-GPU layer runs per rank: each
     rank's forward/backward through the C ABI, the collectives replaced by plain sums."""
     from gat_amd import ops
-    from gat_amd.dist import HipBackend, Partition, local_edges
+    from gat_amd.dist import HipBackend, local_edges, make_partition
     ei, n = cases.GRAPHS[gname]()
     f, h, c = cases.SHAPES[sname]
     x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c)
@@ -686,7 +694,7 @@ def test_partition_kernels_match_oracle(cuda, gname, sname, world):
     cfg = ops.AttnConfig(h, c)
     xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
     asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
-    parts = [Partition(n, world, r) for r in range(world)]
+    parts = [make_partition(ei, n, world, r, balance) for r in range(world)]
     shards = []
     for p in parts:
         hp, a_dst = be.project_fwd(xd[p.lo:p.hi].contiguous(), wd, add_, cfg)
@@ -716,15 +724,16 @@ def test_partition_kernels_match_oracle(cuda, gname, sname, world):
     close(d_b, ref_g["bias"], "d_bias")
 
 
+@pytest.mark.parametrize("balance", ["nodes", "edges"])
 @pytest.mark.parametrize("gname,sname,world", [("multigraph", "conv1_h30", 2), ("star", "products_l1", 3),
                                                ("hub_source", "three_heads", 2), ("knn", "arxiv_l1", 4),
                                                ("multigraph", "in_odd", 3)])
-def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world):
+def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world, balance):
     """Input-side aggregation in rectangular mode (what a rank of the multi-GPU layer runs):
     every rank packs its own rows, the packed table is their concatenation (the all-gather),
     the parameter gradients are the sum over ranks (the all-reduce)."""
     from gat_amd import ops
-    from gat_amd.dist import HipBackend, Partition, local_edges
+    from gat_amd.dist import HipBackend, local_edges, make_partition
     ei, n = cases.GRAPHS[gname]()
     f, h, c = cases.SHAPES[sname]
     x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c)
@@ -734,7 +743,7 @@ def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world):
     cfg.stream = 1 + world % 2          # streaming forward for odd worlds, registers for even
     xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
     asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
-    parts = [Partition(n, world, r) for r in range(world)]
+    parts = [make_partition(ei, n, world, r, balance) for r in range(world)]
     packed = [be.inagg_pack(xd[p.lo:p.hi].contiguous(), wd, asd, add_, cfg) for p in parts]
     table = torch.cat([torch.cat([xs, xs.new_zeros(p.block - p.n_local, xs.size(1))])
                        for p, (xs, _) in zip(parts, packed)])
