@@ -168,7 +168,16 @@ def local_edges(edge_index: Tensor, part: Partition) -> Tensor:
 
 
 # ------------------------------------------------------------------ collectives
+def _host_staged(t: Tensor, group) -> bool:
+    """gloo rehearsals of the GPU path (two ranks sharing one card): stage device tensors through
+    the host ourselves.  gloo's own device path (side streams + pinned copies issued from its
+    worker threads) stalled for seconds to minutes per collective when two processes shared a GPU."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_rows(shard: Tensor, world: int, group=None) -> Tensor:
+    if _host_staged(shard, group):
+        return all_gather_rows(shard.cpu(), world, group).to(shard.device)
     out = shard.new_empty((world * shard.size(0),) + tuple(shard.shape[1:]))
     try:
         dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
@@ -178,6 +187,8 @@ def all_gather_rows(shard: Tensor, world: int, group=None) -> Tensor:
 
 
 def reduce_scatter_rows(full: Tensor, world: int, rank: int, group=None) -> Tensor:
+    if _host_staged(full, group):
+        return reduce_scatter_rows(full.cpu(), world, rank, group).to(full.device)
     out = full.new_empty((full.size(0) // world,) + tuple(full.shape[1:]))
     if dist.get_backend(group) == "gloo":         # gloo has no reduce-scatter: reduce, then slice
         tmp = full.clone()
@@ -188,11 +199,23 @@ def reduce_scatter_rows(full: Tensor, world: int, rank: int, group=None) -> Tens
     return out
 
 
+def all_reduce_(t: Tensor, group=None, op=None) -> Tensor:
+    """in-place all-reduce (sum unless `op`)"""
+    kw = {} if op is None else {"op": op}
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group, **kw)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group, **kw)
+    return t
+
+
 def all_reduce_many(tensors, group=None) -> None:
     """one all-reduce for several small gradients (latency-bound: pack them)."""
     live = [t for t in tensors if t is not None]
     flat = torch.cat([t.reshape(-1) for t in live])
-    dist.all_reduce(flat, group=group)
+    all_reduce_(flat, group)
     off = 0
     for t in live:
         t.copy_(flat[off:off + t.numel()].view_as(t))
@@ -459,15 +482,11 @@ class _SumRanks(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         ctx.group = group
-        y = x.contiguous().clone()
-        dist.all_reduce(y, group=group)
-        return y
+        return all_reduce_(x.contiguous().clone(), group)
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous().clone()
-        dist.all_reduce(g, group=ctx.group)
-        return g, None
+        return all_reduce_(g.contiguous().clone(), ctx.group), None
 
 
 def sync_elu_bn_dropout(x_local: Tensor, bn: nn.BatchNorm1d, p: float, training: bool,
@@ -544,9 +563,7 @@ class PartitionedGAT(nn.Module):
         return torch.nn.functional.nll_loss(logp_local, y_local, reduction="sum") / num_nodes
 
     def global_loss(self, share: Tensor) -> Tensor:
-        total = share.detach().clone()
-        dist.all_reduce(total, group=self.group)
-        return total
+        return all_reduce_(share.detach().clone(), self.group)
 
     def sync_grads(self) -> None:
         all_reduce_many([p.grad for bn in (self.bn1, self.bn2) for p in (bn.weight, bn.bias)],
@@ -582,7 +599,7 @@ def _timed_steps(step, steps, warmup, dev):
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     _lib.prof_enable(False)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    all_reduce_(el, op=dist.ReduceOp.MAX)
     per = {}
     for tag, ms in _lib.prof_read():
         per.setdefault(tag, []).append(ms)
@@ -620,7 +637,7 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     # of a gloo rehearsal was seen to hang.
     shares = torch.zeros(world, 2, device=dev, dtype=torch.int64)
     shares[rank, 0], shares[rank, 1] = layout.num_edges, part.n_local
-    dist.all_reduce(shares)
+    all_reduce_(shares)
     shares = shares.tolist()
     ep = int(sum(s[0] for s in shares))
     mode = conv.resolve_exchange(x, AttnConfig(h, c))
