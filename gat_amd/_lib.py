@@ -109,6 +109,8 @@ SYMBOLS = {
     "gatmi_knn_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gatmi_knn_graph": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
+    "gatmi_knn_graph_ties": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_inagg_supported": (C.c_int, [C.POINTER(Shape)]),
     "gatmi_inagg_z_floats": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_inagg_xs_floats": (C.c_size_t, [C.POINTER(Shape)]),

@@ -12,6 +12,16 @@
 // owns one query (its row in registers, its k best in registers), candidates stream through
 // LDS in tiles and are read by broadcast.  100 k points: 2.5e11 FMA.
 //
+// Ties.  Among candidates at EQUAL distance scikit-learn's order is whatever its bounded max-heap,
+// its final sort, its thread count (1024 x threads queries or fewer: per-thread heaps merged
+// afterwards) and the rounding of its BLAS middle term leave behind -- implementation-defined and
+// host-dependent, so it is detected rather than imitated: with `tie_flags`, the kernel keeps one
+// candidate more than k and marks every query in whose k + 1 best two neighbouring distances are
+// closer than 2^-40 of their magnitude (exact duplicates, and near-ties that scikit-learn's
+// differently rounded surrogate could order the other way).  Unmarked queries have a strictly
+// ordered neighbour list, the one scikit-learn finds; gat_amd.data.create_knn_graph's "auto"
+// backend hands the whole graph to scikit-learn when any query is marked.
+//
 // Output layout = what converter.py:8-15 hands the model: edge_index[0] = the query i, k times
 // in a row, ascending; edge_index[1] = its neighbours by ascending distance (itself first, at
 // distance 0, unless an exact duplicate with a lower index ties).
@@ -35,7 +45,8 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const double *__restrict
 template <int FP, int KK>
 __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ x,
                                                   const double *__restrict__ norms, long long n,
-                                                  int f, int k, long long *__restrict__ edge_index) {
+                                                  int f, int k, long long *__restrict__ edge_index,
+                                                  unsigned char *__restrict__ tie_flags) {
     __shared__ double tile[kKnnTile][FP + 2];         // candidate row | norm | pad (16-byte rows)
     const long long qi = blockIdx.x * 256ll + threadIdx.x;
     const bool qok = qi < n;
@@ -79,24 +90,38 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ x,
         }
     }
     if (qok) {
-        // the list holds KK >= k entries: only the k best are the answer
+        // the list holds KK >= k (+ 1 with tie_flags) entries: only the k best are the answer
 #pragma unroll
         for (int s = 0; s < KK; ++s)
             if (s < k) {
                 edge_index[qi * k + s] = qi;
                 edge_index[n * k + qi * k + s] = bi[s];
             }
+        if (tie_flags) {
+            const double qn = norms[qi];
+            bool tie = false;
+#pragma unroll
+            for (int s = 0; s + 1 < KK; ++s)
+                if (s < k && bi[s + 1] != 0x7fffffff) {       // pairs (0,1) .. (k-1,k) that exist
+                    const double tol = (qn + fabs(bd[s]) + fabs(bd[s + 1])) * 0x1p-40;
+                    tie |= bd[s + 1] - bd[s] <= tol;
+                }
+            tie_flags[qi] = tie ? 1 : 0;
+        }
     }
 }
 
 template <int FP>
 static void knn_launch_k(const double *x, const double *norms, long long n, int f, int k,
-                         long long *ei, hipStream_t st) {
+                         long long *ei, unsigned char *ties, hipStream_t st) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (k <= 8)
-        hipLaunchKernelGGL((knn_kernel<FP, 8>), dim3(blocks), dim3(256), 0, st, x, norms, n, f, k, ei);
+    const int need = k + (ties ? 1 : 0);      // list capacity: one more than k to see a tie at the k-th place
+    if (need <= 8)
+        hipLaunchKernelGGL((knn_kernel<FP, 8>), dim3(blocks), dim3(256), 0, st, x, norms, n, f, k, ei, ties);
+    else if (need <= kKnnMaxK)
+        hipLaunchKernelGGL((knn_kernel<FP, kKnnMaxK>), dim3(blocks), dim3(256), 0, st, x, norms, n, f, k, ei, ties);
     else
-        hipLaunchKernelGGL((knn_kernel<FP, kKnnMaxK>), dim3(blocks), dim3(256), 0, st, x, norms, n, f, k, ei);
+        hipLaunchKernelGGL((knn_kernel<FP, kKnnMaxK + 1>), dim3(blocks), dim3(256), 0, st, x, norms, n, f, k, ei, ties);
 }
 
 }  // namespace gatmi
@@ -109,6 +134,12 @@ extern "C" size_t gatmi_knn_workspace_bytes(int64_t n) {
 
 extern "C" int gatmi_knn_graph(const double *x, int64_t n, int32_t f, int32_t k, int64_t *edge_index,
                                void *ws, size_t ws_bytes, void *stream) {
+    return gatmi_knn_graph_ties(x, n, f, k, edge_index, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int gatmi_knn_graph_ties(const double *x, int64_t n, int32_t f, int32_t k,
+                                    int64_t *edge_index, uint8_t *tie_flags, void *ws,
+                                    size_t ws_bytes, void *stream) {
     GATMI_REQUIRE(n >= 0 && f >= 1 && f <= 64, "knn_graph: features must be in [1, 64]");
     GATMI_REQUIRE(k >= 1 && k <= kKnnMaxK, "knn_graph: k must be in [1, 16]");
     GATMI_REQUIRE(k <= n || n == 0, "knn_graph: k exceeds the number of points (scikit-learn raises too)");
@@ -121,12 +152,12 @@ extern "C" int gatmi_knn_graph(const double *x, int64_t n, int32_t f, int32_t k,
     const int nb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(knn_norms_kernel, dim3(nb), dim3(256), 0, st, x, (long long)n, f, norms);
     long long *ei = reinterpret_cast<long long *>(edge_index);
-    if (f <= 8) knn_launch_k<8>(x, norms, n, f, k, ei, st);
-    else if (f <= 16) knn_launch_k<16>(x, norms, n, f, k, ei, st);
-    else if (f <= 26) knn_launch_k<26>(x, norms, n, f, k, ei, st);
-    else if (f <= 32) knn_launch_k<32>(x, norms, n, f, k, ei, st);
-    else if (f <= 48) knn_launch_k<48>(x, norms, n, f, k, ei, st);
-    else knn_launch_k<64>(x, norms, n, f, k, ei, st);
+    if (f <= 8) knn_launch_k<8>(x, norms, n, f, k, ei, tie_flags, st);
+    else if (f <= 16) knn_launch_k<16>(x, norms, n, f, k, ei, tie_flags, st);
+    else if (f <= 26) knn_launch_k<26>(x, norms, n, f, k, ei, tie_flags, st);
+    else if (f <= 32) knn_launch_k<32>(x, norms, n, f, k, ei, tie_flags, st);
+    else if (f <= 48) knn_launch_k<48>(x, norms, n, f, k, ei, tie_flags, st);
+    else knn_launch_k<64>(x, norms, n, f, k, ei, tie_flags, st);
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }

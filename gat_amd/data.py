@@ -35,10 +35,13 @@ def _values(X) -> np.ndarray:
     return X.values if hasattr(X, "values") else np.asarray(X)
 
 
-def knn_graph_hip(X, k: int = 5, device=None) -> torch.Tensor:
+def knn_graph_hip(X, k: int = 5, device=None, return_ties: bool = False):
     """create_knn_graph on the GPU (gat_amd/csrc/knn.hip): exact fp64 brute force, same
     edge_index layout as the scikit-learn call of /root/reference/gat/converter.py:8-15.
-    Returns an int64 [2, k*N] tensor on `device`."""
+    Returns an int64 [2, k*N] tensor on `device` (default: the current device); with
+    `return_ties` also a bool [N] tensor marking the queries whose neighbour order is not
+    strict (equal or nearly equal distances among the k + 1 nearest: their order in
+    scikit-learn's result is implementation-defined, here the lower index comes first)."""
     from . import _lib
     if not torch.cuda.is_available():
         raise RuntimeError("knn_graph_hip needs a GPU")
@@ -55,30 +58,48 @@ def knn_graph_hip(X, k: int = 5, device=None) -> torch.Tensor:
     lib = _lib.lib()
     with torch.cuda.device(dev):
         ei = torch.empty(2, k * n, dtype=torch.int64, device=dev)
+        ties = torch.zeros(n, dtype=torch.uint8, device=dev) if return_ties else None
         ws = torch.empty(int(lib.gatmi_knn_workspace_bytes(n)), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gatmi_knn_graph(x.data_ptr(), n, f, k, ei.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       torch.cuda.current_stream(dev).cuda_stream), "gatmi_knn_graph")
-    return ei
+        _lib.check(lib.gatmi_knn_graph_ties(x.data_ptr(), n, f, k, ei.data_ptr(),
+                                            None if ties is None else ties.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
+                   "gatmi_knn_graph_ties")
+    return (ei, ties.bool()) if return_ties else ei
 
 
-def create_knn_graph(X, k: int = 5, backend: str = "auto") -> torch.Tensor:
-    """/root/reference/gat/converter.py:7-15; returns a CPU int64 [2, k*N] tensor like the
-    reference.  backend "hip": computed on the GPU (knn_graph_hip keeps the result there);
-    "sklearn": the reference's own scikit-learn call on the host; "auto": "hip" when a GPU is
-    present and the shape is covered (F <= 64, k <= 16), else "sklearn"."""
-    values = _values(X)
-    if backend == "auto":
-        backend = "hip" if (torch.cuda.is_available() and values.ndim == 2 and values.shape[1] <= 64
-                            and k <= 16) else "sklearn"
-    if backend == "hip":
-        return knn_graph_hip(values, k).cpu()
-    if backend != "sklearn":
-        raise ValueError(f"unknown backend {backend!r}")
+def _knn_graph_sklearn(values, k: int) -> torch.Tensor:
     from sklearn.neighbors import kneighbors_graph
     adj = kneighbors_graph(values, n_neighbors=k, mode="connectivity", include_self=True,
                            n_jobs=-1).tocoo()
     pairs = np.vstack([adj.row.astype(np.int64), adj.col.astype(np.int64)])
     return torch.tensor(pairs, dtype=torch.long)
+
+
+def create_knn_graph(X, k: int = 5, backend: str = "auto", device=None) -> torch.Tensor:
+    """/root/reference/gat/converter.py:7-15; returns a CPU int64 [2, k*N] tensor like the
+    reference.  backend "sklearn": the reference's own scikit-learn call on the host.  "hip":
+    computed on the GPU; equal distances resolve towards the lower index (scikit-learn's order
+    among them is implementation-defined).  "auto": the GPU result when a GPU is present, the
+    shape is covered (F <= 64, k <= 16) AND no query has tied neighbours -- then it is bit for bit
+    what scikit-learn returns; with ties (duplicate rows) the whole graph comes from the
+    scikit-learn call, so "auto" always equals the reference's output."""
+    values = _values(X)
+    if backend == "auto":
+        if not (torch.cuda.is_available() and values.ndim == 2 and values.shape[1] <= 64 and k <= 16):
+            backend = "sklearn"
+        else:
+            ei, ties = knn_graph_hip(values, k, device, return_ties=True)
+            tied = int(ties.sum())
+            if tied == 0:
+                return ei.cpu()
+            print(f"[gat_amd] kNN graph: {tied} of {ties.numel()} rows have neighbours at equal distance "
+                  "(duplicate rows); taking scikit-learn's result so that tie order matches the reference")
+            backend = "sklearn"
+    if backend == "hip":
+        return knn_graph_hip(values, k, device).cpu()
+    if backend != "sklearn":
+        raise ValueError(f"unknown backend {backend!r}")
+    return _knn_graph_sklearn(values, k)
 
 
 def convert_to_graph(X, y) -> Data:

@@ -62,7 +62,11 @@ def load_xy():
             z = np.load(path)
             _XY = (pd.DataFrame(z["X"]), pd.Series(z["y"]))
         else:
-            _XY = synthetic_traces(int(os.environ.get("GAT_SYNTH_ROWS", "20000")))
+            rows = int(os.environ.get("GAT_SYNTH_ROWS", "20000"))
+            if world()[0] == 0:     # a run on the stand-in must not be mistaken for one on real traces
+                print(f"[gat_amd] data/traces.csv is not part of the reference repository and GAT_TRACES_NPZ "
+                      f"is not set: training on the SYNTHETIC stand-in table ({rows} rows x 25 features)")
+            _XY = synthetic_traces(rows)
     return _XY
 
 
@@ -76,6 +80,7 @@ def split_data():
     if _GRAPHS is None:
         X_tr, X_te, y_tr, y_te = train_test_split(X, y, test_size=TEST_SIZE, stratify=y,
                                                   random_state=RANDOM_STATE)
+        _bind_device()
         _GRAPHS = (convert_to_graph(X_tr, y_tr), convert_to_graph(X_te, y_te), y_tr, y_te)
     return _GRAPHS
 
@@ -111,6 +116,15 @@ def world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _bind_device() -> None:
+    """Make cuda:LOCAL_RANK this process's current device, so that everything that takes the
+    current device (the kNN graph build of split_data, workspaces) lands on the rank's own GPU
+    instead of every rank opening a context on GPU 0."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+
+
 _CALLS = 0
 
 
@@ -125,6 +139,7 @@ def run_trials(configs: Sequence[Config], experiment: Callable[[Config], ConfigR
     if schedule not in ("static", "dynamic"):
         raise ValueError(f"unknown schedule {schedule!r}")
     rank, size = world()
+    _bind_device()
     if size == 1:
         return [experiment(c) for c in configs]
     import torch.distributed as dist

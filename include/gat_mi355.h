@@ -321,6 +321,14 @@ int gatmi_tail_bwd(int64_t rows, int32_t classes, const float *logp, const int64
 size_t gatmi_knn_workspace_bytes(int64_t n);
 int gatmi_knn_graph(const double *x, int64_t n, int32_t f, int32_t k, int64_t *edge_index,
                     void *ws, size_t ws_bytes, void *stream);
+/* The same, and tie_flags [n] (bytes, NULL to skip) = 1 for every query whose k + 1 nearest hold
+ * two neighbouring distances that agree to 2^-40 of their magnitude: exact duplicates and near-ties,
+ * whose order in scikit-learn's result is implementation-defined (its heap, thread count and BLAS
+ * rounding).  Queries with flag 0 have a strictly ordered list -- the one kneighbors_graph returns;
+ * a caller that needs converter.py:7-15's exact output on tied data recomputes with scikit-learn
+ * when any flag is set (gat_amd.data.create_knn_graph, backend "auto", does). */
+int gatmi_knn_graph_ties(const double *x, int64_t n, int32_t f, int32_t k, int64_t *edge_index,
+                         uint8_t *tie_flags, void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

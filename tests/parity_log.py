@@ -14,8 +14,9 @@ RECORDS = {}
 
 
 def kind_of(name: str) -> str:
-    m = re.search(r"(d_[a-z_]+|out|log-probabilities|h|a_dst|constant rows)", name)
-    return m.group(1) if m else "other"
+    """'trial 3: n=17 h=5 ... d_weight' -> 'd_weight'; the last tensor name in the label"""
+    m = re.findall(r"d_[a-z_]+|log-probabilities|constant rows|\bout\b|\ba_dst\b|\bh$", name)
+    return m[-1] if m else "other"
 
 
 def record(name, got, ref, scale):

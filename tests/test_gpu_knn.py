@@ -62,6 +62,42 @@ def test_knn_graph_with_duplicate_rows(cuda):
     assert (dist(got)[:, 0] == 0).all()
 
 
+def test_auto_backend_is_bit_exact_on_duplicate_rows_too(cuda):
+    """Integer output, bar = bit exact: the default backend flags the queries whose neighbour
+    order is not strict and, when there are any, returns scikit-learn's own graph -- the whole
+    edge_index equals the reference's call, duplicates or not.  Without ties it is the GPU result."""
+    from gat_amd import _lib
+    from gat_amd.data import create_knn_graph, knn_graph_hip
+    rng = np.random.default_rng(11)
+    x = rng.random((400, 25))
+    clean = x.copy()
+    x[50:60] = x[40:50]                       # ten exact duplicates
+    x[200] = x[7]
+    for k in (5, 8, 16):
+        _lib.prof_read(); _lib.prof_enable(True)
+        got = create_knn_graph(x, k)          # backend="auto"
+        _lib.prof_enable(False)
+        assert "knn_graph" in {t for t, _ in _lib.prof_read()}
+        np.testing.assert_array_equal(got.numpy(), sklearn_edge_index(x, k))
+    # which rows are flagged: exactly those with a tie among their k + 1 nearest
+    ei, ties = knn_graph_hip(x, 5, device=cuda, return_ties=True)
+    d = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(-1))
+    near = np.sort(d, axis=1)[:, :6]
+    want = (np.diff(near, axis=1) <= 1e-12).any(1)
+    assert want.sum() >= 22                    # the 22 duplicated points at least
+    np.testing.assert_array_equal(ties.cpu().numpy(), want)
+    # no duplicates: nothing flagged, and auto IS the GPU result
+    ei, ties = knn_graph_hip(clean, 5, device=cuda, return_ties=True)
+    assert not bool(ties.any())
+    np.testing.assert_array_equal(create_knn_graph(clean, 5).numpy(), ei.cpu().numpy())
+    np.testing.assert_array_equal(ei.cpu().numpy(), sklearn_edge_index(clean, 5))
+    # a near-tie (two candidates 1e-14 apart) is flagged as well
+    y = clean.copy()
+    y[300] = y[20] * (1 + 1e-15) + 1e-16
+    _, ties = knn_graph_hip(y, 5, device=cuda, return_ties=True)
+    assert bool(ties[20]) and bool(ties[300])
+
+
 def test_knn_graph_rejects_bad_arguments(cuda):
     from gat_amd.data import knn_graph_hip
     x = np.random.default_rng(0).random((4, 3))

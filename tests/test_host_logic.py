@@ -118,3 +118,81 @@ def test_trials_shard_one_per_rank_and_merge_in_order():
     assert got[0][1] == want[0::2] and got[1][1] == want[1::2]     # disjoint round-robin shards
     for _, _, scores, lrs in got:                                   # every rank sees all, in order
         assert scores == want and lrs == want
+
+
+# ------------------------------------------------------------------ search drivers (host logic)
+def test_monte_carlo_draws_follow_the_reference_ranges():
+    import monte_carlo_search as mc
+    a, b = mc.sample_configs(50, seed=3), mc.sample_configs(50, seed=3)
+    assert [c.__dict__ for c in a] == [c.__dict__ for c in b]            # every rank draws the same list
+    assert a[0].__dict__ != mc.sample_configs(1, seed=4)[0].__dict__
+    for c in a:                                                          # monte_carlo_search.py:154-162
+        assert 0.03 <= c.lr <= 0.05 and 4.5e-4 <= c.weight_decay <= 6e-4 and 0.4 <= c.dropout <= 0.45
+        assert c.epochs in (25, 35) and c.patience in (3, 7) and c.hidden_dim in (24, 40)
+        assert c.optimizer is torch.optim.AdamW
+    assert len({c.lr for c in a}) == 50                                  # continuous, not a grid
+
+
+def test_evolutionary_search_breeds_as_the_reference_does():
+    import random
+    import evolutionary_computing_search as ev
+    rng = random.Random(0)
+    pop = ev.create_initial_population(10, ev.RANGES, rng)
+    assert len(pop) == 10 and all(c.lr in ev.RANGES["lr"] and c.dropout in ev.RANGES["dropout"] for c in pop)
+    a, b = pop[0], pop[1]
+    for child in ev.crossover_configs(a, b, rng):
+        for name in ev.FIELDS:
+            assert getattr(child, name) in (getattr(a, name), getattr(b, name))
+    m = ev.mutate_config(ev.Config(**a.__dict__), ev.RANGES, rng, rate=1.0)   # every field redrawn, in range
+    assert m.lr in ev.RANGES["lr"] and 0.00046 <= m.weight_decay <= 0.00052 and m.optimizer is a.optimizer
+    scored = [(i / 10.0, c) for i, c in enumerate(pop)]
+    nxt = ev.next_population(scored, ev.RANGES, rng)
+    assert len(nxt) == 15                                                # 5 survivors, 2 children each (:174-183)
+    assert [nxt[i] for i in (0, 3, 6, 9, 12)] == [pop[i] for i in (9, 8, 7, 6, 5)]   # best first
+
+    seen = []
+
+    def evaluate(population):           # score: prefers wide layers and lr 0.04
+        seen.append(len(population))
+        return [c.hidden_dim / 36.0 - abs(c.lr - 0.04) for c in population]
+
+    best, score = ev.evolutionary_search(ev.RANGES, evaluate, seed=1)
+    best2, score2 = ev.evolutionary_search(ev.RANGES, evaluate, seed=1)
+    assert seen[:6] == [10, 15, 15, 15, 15, 15]                          # one training per population
+    assert best.__dict__ == best2.__dict__ and score == score2
+    assert best.hidden_dim == 36 and score > 0.99
+
+
+def _evo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import evolutionary_computing_search as ev
+    from gat_amd import trials
+    ran = []
+
+    def fake(cfg):
+        ran.append(cfg.lr)
+        s = cfg.hidden_dim / 36.0 - abs(cfg.lr - 0.04)
+        return trials.ConfigResults(cfg, [Metrics()], s, 1.0, 1.0, s, s, s, s)
+
+    def evaluate(population):
+        return [r.composite_score for r in trials.run_trials(population, fake, schedule="dynamic")]
+
+    best, score = ev.evolutionary_search(ev.RANGES, evaluate, seed=2, generations=2)
+    q.put((rank, len(ran), best.__dict__["hidden_dim"], best.lr, score))
+    dist.destroy_process_group()
+
+
+def test_evolutionary_generations_shard_over_ranks_and_agree():
+    """A generation's evaluations go through the shared trial queue (one per rank at a time); both
+    ranks breed the same next generation from the gathered scores and end with the same best."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_evo_worker, args=(r, 2, 29625, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert got[0][1] + got[1][1] == 10 + 15 + 15          # every configuration evaluated once, somewhere
+    assert got[0][1] > 0 and got[1][1] > 0
+    assert got[0][2:] == got[1][2:]
