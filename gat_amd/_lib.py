@@ -43,7 +43,7 @@ class Shape(C.Structure):
 
 class Attn(C.Structure):
     _fields_ = [("shape", Shape), ("negative_slope", C.c_float), ("dropout_p", C.c_float),
-                ("mask_mode", C.c_int32), ("_pad", C.c_int32), ("seed", C.c_uint64),
+                ("mask_mode", C.c_int32), ("feat_bf16", C.c_int32), ("seed", C.c_uint64),
                 ("mask", C.c_void_p), ("hp", C.c_void_p), ("a_dst", C.c_void_p),
                 ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
 
@@ -87,6 +87,8 @@ SYMBOLS = {
     "gatmi_dropout_mask": (C.c_int, [C.POINTER(Graph), C.c_int, C.c_float, C.c_uint64, C.c_void_p,
                                      C.c_void_p]),
     "gatmi_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
+    "gatmi_attn_bf16_supported": (C.c_int, [C.POINTER(Shape)]),
+    "gatmi_attn_bwd_workspace_bytes_bf16": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_attn_bwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

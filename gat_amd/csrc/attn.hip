@@ -30,9 +30,11 @@ struct RowArgs {
     float neg_slope, p_drop, inv_keep;
     uint32_t keep_thr;     // p * 2^24
     int mask_mode;
+    int feat_bf16;         // hp / hself are bf16 tables (G == 64 layouts only)
     const uint8_t *mask;
     uint64_t seed;
-    const float *hp;       // fwd/passA: projected features; passB: padded grad_out
+    const void *hp;        // fwd: projected features; bwd edge pass: padded grad_out -- f32 or bf16
+                           // rows (the kernel's RAW type), [N, Dp]
     const float *a_dst;
     const float *att_src;
     const float *att_dst;
@@ -42,7 +44,7 @@ struct RowArgs {
     float *lse;
     float *part_m, *part_s, *part_acc;
     // backward edge pass (transposed CSR; hp = padded grad_out there)
-    const float *hself;    // [N, Dp] projected features (row-local)
+    const void *hself;     // [N, Dp] projected features (row-local), same element type as hp
     const float *nodeinfo; // [N, H, 4] (a_dst, lse, S, 0)
     float *du_t;           // [E', H] d_u in transposed-CSR order
     float *dhp;            // [N, Dp]
@@ -79,7 +81,7 @@ struct RowArgs {
 // Loads are branch-free: batch slots past the row's end re-read its last edge with
 // weight exp(-inf) = 0, idle lanes read offset 0.
 // ---------------------------------------------------------------------------------
-template <int LPH2_T, int G, int T>
+template <int LPH2_T, int G, int T, class RAW>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
     constexpr int U = (T == 1) ? GATMI_U : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
@@ -101,15 +103,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
         const int cl = min(lig, n - 1);
         const int cj = A.col[c + cl];
         const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
-        auto load = [&](float4(&v)[U][T], int k0) {
+        auto load = [&](RAW(&v)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = group_bcast<G>(cj, min(k0 + u, n - 1), gbase);
 #pragma unroll
-                for (int t = 0; t < T; ++t) v[u][t] = ld4_row<G>(A.hp, j, A.Dp, offb[t]);
+                for (int t = 0; t < T; ++t) v[u][t] = ld_slot<G, RAW>(A.hp, j, A.Dp, offb[t]);
             }
         };
-        auto reduce = [&](const float4(&v)[U][T], int k0) {
+        auto reduce = [&](const RAW(&raw)[U][T], int k0) {
+            float4 v[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[u][t] = widen(raw[u][t]);
             float z[U][T];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
                 }
             }
         };
-        float4 va[U][T], vb[U][T];
+        RAW va[U][T], vb[U][T];
         load(va, 0);
         for (int k0 = 0; k0 < n; k0 += 2 * U) {
             load(vb, k0 + U);
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
 __global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
     const float *gout, const float *outc, const float *bias, const float *a_dst, const float *lse,
     long long nq /* float4 count = N*Dp/4 */, int H, int lph_log, int nslot, float4 *nodeinfo,
-    float *gsum_partial) {
+    float *gsum_partial, bf16x4 *g16 /* NULL, or the bf16 copy the edge pass gathers */) {
     const int lph = 1 << lph_log;
     const long long stride = (long long)gridDim.x * 256;   // multiple of nslot
     const int slot = threadIdx.x & (nslot - 1);
@@ -265,9 +272,15 @@ __global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
             const long long q = q0 + u * stride;
             float4 o = o4[u];
             o.x -= b4.x; o.y -= b4.y; o.z -= b4.z; o.w -= b4.w;
-            float p = dot4(g4[u], o);
-            for (int w = 1; w < lph; w <<= 1) p += __shfl_xor(p, w, 64);
             gsum.x += g4[u].x; gsum.y += g4[u].y; gsum.z += g4[u].z; gsum.w += g4[u].w;
+            float4 gq = g4[u];
+            if (g16) {          // the edge pass sees grad_out rounded to bf16: so does S (d_bias does not)
+                const bf16x4 r = narrow(gq);
+                if (q < nq) g16[q] = r;
+                gq = widen(r);
+            }
+            float p = dot4(gq, o);
+            for (int w = 1; w < lph; w <<= 1) p += __shfl_xor(p, w, 64);
             if (q < nq && (q & (lph - 1)) == 0) {
                 const long long grp = q >> lph_log;
                 nodeinfo[grp] = make_float4(a_dst[grp], lse[grp], p, 0.f);
@@ -290,7 +303,8 @@ __global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
 __global__ __launch_bounds__(256) void bwd_prep_kernel(
     const float *gout, const float *outc, const float *bias, const float *a_dst, const float *lse,
     int N, int H, int C, int Cp, int Dp, float4 *nodeinfo, float *gp,
-    float *gsum_partial /* [blocks, Dp]: column sums of grad_out, for d_bias */) {
+    float *gsum_partial /* [blocks, Dp]: column sums of grad_out, for d_bias */,
+    bf16x4 *g16 /* NULL, or [N, Dp] bf16: the padded copy the edge pass gathers instead of gp */) {
     __shared__ float part[256];
     const int nslot = Dp >> 2;
     const int rows_per_pass = 256 / nslot;
@@ -315,9 +329,16 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
             const float4 g4 = ldc(gout + r * H * C + coff, nval, vec_ok);
             float4 o4 = ldc(outc + r * H * C + coff, nval, vec_ok);
             o4.x -= b4.x; o4.y -= b4.y; o4.z -= b4.z; o4.w -= b4.w;
-            p = dot4(g4, o4);
             gsum.x += g4.x; gsum.y += g4.y; gsum.z += g4.z; gsum.w += g4.w;
-            if (gp) st4(gp + r * Dp + slot * 4, g4);
+            float4 gq = g4;
+            if (g16) {
+                const bf16x4 rr = narrow(g4);
+                g16[r * (Dp >> 2) + slot] = rr;
+                gq = widen(rr);
+            } else if (gp) {
+                st4(gp + r * Dp + slot * 4, g4);
+            }
+            p = dot4(gq, o4);
         }
         part[threadIdx.x] = p;
         __syncthreads();
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
     }
 }
 
-template <int LPH2_T, int G, int T>
+template <int LPH2_T, int G, int T, class RAW>
 __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
     constexpr int U = (T == 1) ? GATMI_U : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
-        hj[t] = S.nval[t] ? ld4(A.hself + (size_t)row * A.Dp + S.poff[t])
+        hj[t] = S.nval[t] ? ld_own<RAW>(A.hself, (size_t)row, A.Dp, S.poff[t])
                           : make_float4(0.f, 0.f, 0.f, 0.f);
         asj[t] = head_sum<LPH2_T>(dot4(hj[t], att[t]), lph2);
         acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -368,18 +389,23 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
         const int ci = A.col[c + cl];
         const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
                                       (long long)A.aux[c + cl], A.H);
-        auto load = [&](float4(&v)[U][T], float4(&q)[U][T], int k0) {
+        auto load = [&](RAW(&v)[U][T], float4(&q)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = group_bcast<G>(ci, min(k0 + u, n - 1), gbase);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    v[u][t] = ld4_row<G>(A.hp, i, A.Dp, offb[t]);
+                    v[u][t] = ld_slot<G, RAW>(A.hp, i, A.Dp, offb[t]);
                     q[u][t] = ld4_row<G>(A.nodeinfo, i, A.H * 4, noff[t]);
                 }
             }
         };
-        auto reduce = [&](const float4(&v)[U][T], const float4(&q)[U][T], int k0) {
+        auto reduce = [&](const RAW(&raw)[U][T], const float4(&q)[U][T], int k0) {
+            float4 v[U][T];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[u][t] = widen(raw[u][t]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool live = k0 + u < n;
@@ -400,7 +426,8 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
                 }
             }
         };
-        float4 va[U][T], vb[U][T], qa[U][T], qb[U][T];
+        RAW va[U][T], vb[U][T];
+        float4 qa[U][T], qb[U][T];
         load(va, qa, 0);
         for (int k0 = 0; k0 < n; k0 += 2 * U) {
             load(vb, qb, k0 + U);
@@ -504,8 +531,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dst_merge_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int kColsumBlocks = 1024;
 
+template <class RAW>
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(
-    const float *hp, const float *da_src, const float *da_dst, const float *att_dst,
+    const void *hp, const float *da_src, const float *da_dst, const float *att_dst,
     float *dhp /* NULL: no fix-up */, int n_src, int n_dst, int dst_off, int H, int C, int Cp,
     int Dp, float *partial /* [blocks, 2, Dp] */) {
     __shared__ float4 red[2][256];
@@ -533,12 +561,12 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
         for (long long r = r0 + rsub; r < r1; r += rows_per_pass) {
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < n_src) {
-                hv = ld4(hp + r * Dp + slot * 4);
+                hv = ld_own<RAW>(hp, (size_t)r, Dp, slot * 4);
                 fma4(a, da_src[r * H + head], hv);
             }
             if (r < n_dst) {
                 const float dd = da_dst[r * H + head];
-                if (!same) hv = ld4(hp + (r + dst_off) * Dp + slot * 4);
+                if (!same) hv = ld_own<RAW>(hp, (size_t)(r + dst_off), Dp, slot * 4);
                 fma4(b, dd, hv);
                 if (dhp) {  // d_h[r] += d_a_dst[r] att_dst
                     float4 dh = ld4(dhp + (r + dst_off) * Dp + slot * 4);
@@ -653,10 +681,19 @@ enum Kind { FWD, BWD_EDGE };
 
 template <int LPH2_T, int G, int T>
 static void launch_kind(Kind k, const RowArgs &A, int grid, hipStream_t st) {
+    if constexpr (G == 64) {      // bf16 feature tables: full-wave rows only (make_geometry.G == 64)
+        if (A.feat_bf16) {
+            if (k == FWD)
+                hipLaunchKernelGGL((attn_fwd_kernel<LPH2_T, G, T, bf16x4>), dim3(grid), dim3(256), 0, st, A);
+            else
+                hipLaunchKernelGGL((attn_bwd_edge_kernel<LPH2_T, G, T, bf16x4>), dim3(grid), dim3(256), 0, st, A);
+            return;
+        }
+    }
     if (k == FWD)
-        hipLaunchKernelGGL((attn_fwd_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
+        hipLaunchKernelGGL((attn_fwd_kernel<LPH2_T, G, T, float4>), dim3(grid), dim3(256), 0, st, A);
     else
-        hipLaunchKernelGGL((attn_bwd_edge_kernel<LPH2_T, G, T>), dim3(grid), dim3(256), 0, st, A);
+        hipLaunchKernelGGL((attn_bwd_edge_kernel<LPH2_T, G, T, float4>), dim3(grid), dim3(256), 0, st, A);
 }
 
 static int launch_rows(Kind k, const Geometry &g, const RowArgs &A, hipStream_t st) {
@@ -715,6 +752,7 @@ static void fill_common(RowArgs &A, const gatmi_attn &a, const Geometry &g) {
     if (a.mask_mode == GATMI_MASK_NONE) A.inv_keep = 1.0f;
     A.keep_thr = (uint32_t)((double)a.dropout_p * 16777216.0);
     A.mask_mode = a.mask_mode;
+    A.feat_bf16 = a.feat_bf16 ? 1 : 0;
     A.mask = a.mask;
     A.seed = a.seed;
     A.hp = a.hp;
@@ -741,6 +779,10 @@ static int check_attn(const gatmi_graph *g, const gatmi_attn *a) {
     GATMI_REQUIRE(a->mask_mode == GATMI_MASK_NONE || a->shape.heads <= 32,
                   "attention dropout supports at most 32 heads, got %d", a->shape.heads);
     GATMI_REQUIRE(a->hp && a->a_dst && a->att_src, "null hp/a_dst/att_src");
+    GATMI_REQUIRE(!a->feat_bf16 || gatmi_attn_bf16_supported(&a->shape),
+                  "bf16 feature tables need rows of more than 32 float4 slots (heads * "
+                  "next_pow2(round_up(channels, 4) / 4) > 32): got %d x %d", a->shape.heads,
+                  a->shape.channels);
     return GATMI_OK;
 }
 
@@ -880,15 +922,20 @@ extern "C" int gatmi_attn_fwd_static(const gatmi_graph *g, const gatmi_attn *a, 
 namespace {
 struct BwdWs {
     float *nodeinfo, *du_t, *gp, *da_dst, *da_src, *part_dad, *part_das, *part_dh, *colsum;
+    bf16x4 *g16;
     size_t bytes;
 };
-BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws) {
+BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws,
+                bool feat_bf16) {
     Carver cv(ws);
     BwdWs w;
     const size_t N = (size_t)g->num_dst, NS = (size_t)g->num_src, H = (size_t)s->heads;
     w.nodeinfo = cv.take<float>(N * H * 4);
     w.du_t = cv.take<float>((size_t)g->num_edges * H);
-    w.gp = (s->channels & 3) ? cv.take<float>(N * geo.Dp) : nullptr;
+    // the grad_out rows the edge pass gathers: grad_out itself, a padded f32 copy (C % 4 != 0),
+    // or -- bf16 feature tables -- a padded bf16 copy at half the bytes
+    w.gp = (!feat_bf16 && (s->channels & 3)) ? cv.take<float>(N * geo.Dp) : nullptr;
+    w.g16 = feat_bf16 ? cv.take<bf16x4>(N * geo.Dp / 4) : nullptr;
     w.da_dst = cv.take<float>(N * H);
     w.da_src = cv.take<float>(NS * H);
     w.part_dad = cv.take<float>((size_t)g->plan.n_slots * H);
@@ -903,7 +950,18 @@ BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo,
 extern "C" size_t gatmi_attn_bwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s) {
     Geometry geo;
     if (!g || !s || make_geometry(*s, &geo)) return 0;
-    return carve_bwd(g, s, geo, nullptr).bytes;
+    return carve_bwd(g, s, geo, nullptr, false).bytes;
+}
+
+extern "C" size_t gatmi_attn_bwd_workspace_bytes_bf16(const gatmi_graph *g, const gatmi_shape *s) {
+    Geometry geo;
+    if (!g || !s || make_geometry(*s, &geo)) return 0;
+    return carve_bwd(g, s, geo, nullptr, true).bytes;
+}
+
+extern "C" int gatmi_attn_bf16_supported(const gatmi_shape *s) {
+    Geometry geo;
+    return s && make_geometry(*s, &geo) == GATMI_OK && geo.G == 64;
 }
 
 extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
@@ -914,13 +972,15 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     Geometry geo;
     if (int e = make_geometry(a->shape, &geo)) return e;
     GATMI_REQUIRE(out && lse && grad_out && d_hp && a->att_dst, "null out/lse/grad_out/d_hp/att_dst");
-    const size_t need = gatmi_attn_bwd_workspace_bytes(g, &a->shape);
+    const bool bf = a->feat_bf16 != 0;
+    const size_t need = bf ? gatmi_attn_bwd_workspace_bytes_bf16(g, &a->shape)
+                           : gatmi_attn_bwd_workspace_bytes(g, &a->shape);
     if (ws_bytes < need) {
         set_error("attn_bwd workspace too small: %zu < %zu", ws_bytes, need);
         return GATMI_ERR_WS;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const BwdWs w = carve_bwd(g, &a->shape, geo, ws);
+    const BwdWs w = carve_bwd(g, &a->shape, geo, ws, bf);
     const int N = g->num_dst, NS = g->num_src, H = a->shape.heads, C = a->shape.channels;
     GATMI_REQUIRE(d_a_dst_out || N == NS,
                   "a destination partition must take d_a_dst (the d_h fix-up follows its reduce-scatter)");
@@ -936,16 +996,17 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
             hipLaunchKernelGGL(bwd_prep_flat_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out,
                                out, a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H,
                                geo.lph2_log, geo.Dp / 4, reinterpret_cast<float4 *>(w.nodeinfo),
-                               gsum_partial);
+                               gsum_partial, w.g16);
             GATMI_HIP(hipGetLastError());
         } else if (N > 0) {
             hipLaunchKernelGGL(bwd_prep_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
                                a->bias, a->a_dst, lse, N, H, C, geo.Cp, geo.Dp,
-                               reinterpret_cast<float4 *>(w.nodeinfo), w.gp, gsum_partial);
+                               reinterpret_cast<float4 *>(w.nodeinfo), w.gp, gsum_partial, w.g16);
             GATMI_HIP(hipGetLastError());
         }
     }
-    const float *gpad = w.gp ? w.gp : grad_out;
+    const void *gpad = w.g16 ? static_cast<const void *>(w.g16)
+                             : static_cast<const void *>(w.gp ? w.gp : grad_out);
 
     RowArgs B;
     fill_common(B, *a, geo);
@@ -997,9 +1058,14 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     {
         ProfScope ps("param_colsum", st);
         const int blocks = NS < kColsumBlocks ? NS : kColsumBlocks;
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(blocks), dim3(256), 0, st, a->hp, w.da_src,
-                           w.da_dst, a->att_dst, d_a_dst_out ? nullptr : d_hp, NS, N,
-                           g->dst_offset, H, C, geo.Cp, geo.Dp, w.colsum);
+        if (bf)
+            hipLaunchKernelGGL(colsum_stage1_kernel<bf16x4>, dim3(blocks), dim3(256), 0, st, a->hp,
+                               w.da_src, w.da_dst, a->att_dst, d_a_dst_out ? nullptr : d_hp, NS, N,
+                               g->dst_offset, H, C, geo.Cp, geo.Dp, w.colsum);
+        else
+            hipLaunchKernelGGL(colsum_stage1_kernel<float4>, dim3(blocks), dim3(256), 0, st, a->hp,
+                               w.da_src, w.da_dst, a->att_dst, d_a_dst_out ? nullptr : d_hp, NS, N,
+                               g->dst_offset, H, C, geo.Cp, geo.Dp, w.colsum);
         GATMI_HIP(hipGetLastError());
         if (d_att_src || d_att_dst || d_bias) {
             hipLaunchKernelGGL(colsum_stage2_kernel, dim3((geo.Dp + 15) / 16, 3), dim3(256), 0, st,

@@ -166,6 +166,62 @@ __device__ __forceinline__ float4 ld4_row(const float *table, int j, int row_flo
     }
 }
 
+// ---- bf16 feature tables (gatmi_attn.feat_bf16): the same head-padded rows at 2 bytes per
+// channel.  A lane's slot is 4 channels = 8 bytes; values are widened to f32 in registers and all
+// arithmetic stays f32.
+struct bf16x4 { uint32_t lo, hi; };   // channels (0,1) and (2,3), low half first
+
+__device__ __forceinline__ float4 widen(const bf16x4 &r) {
+    return make_float4(__uint_as_float(r.lo << 16), __uint_as_float(r.lo & 0xffff0000u),
+                       __uint_as_float(r.hi << 16), __uint_as_float(r.hi & 0xffff0000u));
+}
+__device__ __forceinline__ float4 widen(const float4 &r) { return r; }
+
+// two f32 -> packed bf16, round to nearest even (what torch's .to(torch.bfloat16) does)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ bf16x4 narrow(const float4 &v) {
+    return bf16x4{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+}
+// v rounded to bf16 and widened again: the value a bf16 table hands back
+__device__ __forceinline__ float4 round_bf16(const float4 &v) { return widen(narrow(v)); }
+
+// This lane's slot of row j of a table of type RAW (float4: f32 table, bf16x4: bf16 table);
+// off_bytes is the slot's byte offset in an f32 row.  See ld4_row.
+template <int G, class RAW>
+__device__ __forceinline__ RAW ld_slot(const void *table, int j, int row_floats, unsigned off_bytes) {
+    if constexpr (sizeof(RAW) == 16) {
+        return ld4_row<G>(static_cast<const float *>(table), j, row_floats, off_bytes);
+    } else {
+        const char *rowp = static_cast<const char *>(table) + (size_t)j * (size_t)row_floats * 2;
+        if constexpr (G == 64) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(rowp), 0, row_floats * 2, 0x00020000);
+            const u32x2 r = __builtin_bit_cast(
+                u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off_bytes >> 1), 0, 0));
+            return bf16x4{r[0], r[1]};
+        } else {
+            const uint2 r = *reinterpret_cast<const uint2 *>(rowp + (off_bytes >> 1));
+            return bf16x4{r.x, r.y};
+        }
+    }
+}
+// the same slot of a row this lane owns itself (plain load)
+template <class RAW>
+__device__ __forceinline__ float4 ld_own(const void *table, size_t row, int row_floats, int poff) {
+    if constexpr (sizeof(RAW) == 16) {
+        return ld4(static_cast<const float *>(table) + row * row_floats + poff);
+    } else {
+        const uint2 r = *reinterpret_cast<const uint2 *>(
+            static_cast<const uint16_t *>(table) + row * row_floats + poff);
+        return widen(bf16x4{r.x, r.y});
+    }
+}
+
 // blockIdx -> work position such that blocks sharing an XCD (equal blockIdx % 8)
 // walk a contiguous range of work items.  gridDim.x is a multiple of 8.
 __device__ __forceinline__ int xcd_contiguous_block() {

@@ -38,12 +38,16 @@ class AttnConfig:
         self.negative_slope, self.dropout = float(negative_slope), float(dropout)
         self.mask_mode, self.seed, self.mask = mask_mode, seed, mask
         self.stream = 0     # input-side aggregation forward: 0 auto, 1 streaming, 2 registers
+        self.feat_bf16 = False   # projected-row path: hp is a bfloat16 table (attn_bf16_supported)
 
     def c_args(self, num_dst, in_features, hp, a_dst, att_src, att_dst, bias):
         a = _lib.Attn()
         a.shape = _lib.Shape(num_dst, in_features, self.heads, self.channels)
         a.negative_slope, a.dropout_p = self.negative_slope, self.dropout
         a.mask_mode, a.seed, a.mask = self.mask_mode, self.seed, _ptr(self.mask)
+        if (hp.dtype == torch.bfloat16) != bool(self.feat_bf16):
+            raise TypeError(f"feature table is {hp.dtype} but feat_bf16={self.feat_bf16}")
+        a.feat_bf16 = int(bool(self.feat_bf16))
         a.hp, a.a_dst = _ptr(hp), _ptr(a_dst)
         a.att_src, a.att_dst, a.bias = _ptr(att_src), _ptr(att_dst), _ptr(bias)
         return a
@@ -113,12 +117,19 @@ def attn_bwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor,
         d_b = torch.empty_like(bias) if bias is not None else None
         d_a_dst = (torch.empty(layout.num_dst, cfg.heads, dtype=torch.float32, device=dev)
                    if defer_dst_term else None)
-        ws = _ws(lib.gatmi_attn_bwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
+        query = lib.gatmi_attn_bwd_workspace_bytes_bf16 if cfg.feat_bf16 else lib.gatmi_attn_bwd_workspace_bytes
+        ws = _ws(query(layout.ref, C.byref(a.shape)), dev)
         _lib.check(lib.gatmi_attn_bwd(layout.ref, C.byref(a), out.data_ptr(), lse.data_ptr(),
                                       grad_out.data_ptr(), d_hp.data_ptr(), d_as.data_ptr(),
                                       d_ad.data_ptr(), _ptr(d_b), _ptr(d_a_dst), ws.data_ptr(),
                                       ws.numel(), _stream(dev)), "gatmi_attn_bwd")
     return d_hp, d_as, d_ad, d_b, d_a_dst
+
+
+def attn_bf16_supported(heads: int, channels: int) -> bool:
+    """True when the fused attention kernels take a bfloat16 feature table for this layer."""
+    shape = _lib.Shape(0, 1, heads, channels)
+    return bool(_lib.lib().gatmi_attn_bf16_supported(C.byref(shape)))
 
 
 def add_dst_term(d_hp: Tensor, d_a_dst: Tensor, att_dst: Tensor, heads: int, channels: int) -> None:

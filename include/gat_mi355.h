@@ -150,10 +150,10 @@ typedef struct gatmi_attn {
     float negative_slope;  /* LeakyReLU slope, GATConv default 0.2 */
     float dropout_p;       /* attention dropout probability (model.py:26,28,30)      */
     int32_t mask_mode;     /* GATMI_MASK_*                                            */
-    int32_t _pad;
+    int32_t feat_bf16;     /* 0: hp is float32; 1: hp is bfloat16 (see "bf16 feature tables") */
     uint64_t seed;         /* GATMI_MASK_HASH                                         */
     const uint8_t *mask;   /* GATMI_MASK_BYTES: [E', H] keep flags, dst-CSR order     */
-    const float *hp;       /* [N, Dp] projected features                              */
+    const void *hp;        /* [N, Dp] projected features, float32 or bfloat16         */
     const float *a_dst;    /* [N, H]                                                  */
     const float *att_src;  /* [H*C]                                                   */
     const float *att_dst;  /* [H*C]   (backward only)                                 */
@@ -202,6 +202,19 @@ int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
                    const float *lse, const float *grad_out, float *d_hp,
                    float *d_att_src, float *d_att_dst, float *d_bias, float *d_a_dst_out,
                    void *ws, size_t ws_bytes, void *stream);
+
+/* ---- bf16 feature tables (BASELINE.json north_star: "bf16 stated separately").  The edge
+ * kernels are bound by the bytes of the rows they gather, so the projected features can be kept
+ * as bfloat16 rows (same head-padded layout, 2 bytes per channel): gatmi_attn.feat_bf16 = 1 and
+ * hp = the bf16 table gatmi_project_fwd_bf16 writes.  Every value is widened to f32 in registers;
+ * logits, softmax, accumulation, out, lse and all gradients stay f32.  The backward gathers
+ * grad_out rows from a bf16 copy it makes itself (S_i is taken from the same rounded rows, d_bias
+ * from the unrounded ones), so the gradients are those of the function "h and the gradient
+ * arriving at the aggregate rounded to bf16" -- tests state that tolerance separately from the
+ * f32 path's.  Needs rows of more than 32 float4 slots (gatmi_attn_bf16_supported); the backward
+ * workspace is gatmi_attn_bwd_workspace_bytes_bf16. */
+int gatmi_attn_bf16_supported(const gatmi_shape *s);
+size_t gatmi_attn_bwd_workspace_bytes_bf16(const gatmi_graph *g, const gatmi_shape *s);
 
 /* d_hp[i, h, :] += d_a_dst[i, h] * att_dst[h, :] for i < s->num_nodes (rows of one shard). */
 int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float *d_a_dst,

@@ -134,11 +134,36 @@ def segment_softmax(z: torch.Tensor, index: torch.Tensor, num_nodes: int) -> tor
     return out / out_sum.index_select(0, index)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """y = x rounded to bfloat16 (nearest even), gradient passed straight through."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    """y = x; the gradient arriving at y is rounded to bfloat16 on its way to x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 def gatconv_forward(x, edge_index, weight, att_src, att_dst, bias, heads, out_channels,
                     negative_slope: float = NEG_SLOPE_DEFAULT, dropout: float = 0.0,
                     training: bool = False, mask: Optional[torch.Tensor] = None,
                     add_self_loops: bool = True, concat: bool = True,
-                    return_intermediates: bool = False):
+                    return_intermediates: bool = False, bf16_tables: bool = False,
+                    bf16_matmul: bool = False):
     """One GATConv.forward (model.py:40,43,46).
 
     ``mask`` -- optional {0,1} tensor [E', H] in normalised-edge-list order.  Given,
@@ -147,7 +172,13 @@ def gatconv_forward(x, edge_index, weight, att_src, att_dst, bias, heads, out_ch
     """
     n = x.size(0)
     h_, c_ = heads, out_channels
-    h = F.linear(x, weight).view(n, h_, c_)                      # lin(x), no bias
+    if bf16_matmul:      # bf16 MFMA projection: operands rounded to bf16, products accumulated wider
+        h = F.linear(_RoundBF16.apply(x), _RoundBF16.apply(weight))
+    else:
+        h = F.linear(x, weight)                                  # lin(x), no bias
+    if bf16_tables:      # the feature rows are STORED as bf16 (the reference has no such mode: this
+        h = _RoundBF16.apply(h)   # models libgat_mi355's bf16 feature tables, rounding points included)
+    h = h.view(n, h_, c_)
     a_s = (h * att_src.view(1, h_, c_)).sum(dim=-1)              # [N, H]
     a_d = (h * att_dst.view(1, h_, c_)).sum(dim=-1)
     ei = normalize_edges(edge_index, n) if add_self_loops else edge_index
@@ -162,6 +193,8 @@ def gatconv_forward(x, edge_index, weight, att_src, att_dst, bias, heads, out_ch
     msg = alpha_t.unsqueeze(-1) * h.index_select(0, src)         # [E', H, C]
     out = torch.zeros(n, h_, c_, dtype=x.dtype).scatter_add_(
         0, dst.view(-1, 1, 1).expand_as(msg), msg)
+    if bf16_tables:      # the backward gathers grad_out rows from a bf16 copy
+        out = _RoundGradBF16.apply(out)
     out = out.view(n, h_ * c_) if concat else out.mean(dim=1)
     if bias is not None:
         out = out + bias
