@@ -88,6 +88,13 @@ SYMBOLS = {
                                      C.c_void_p]),
     "gatmi_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_attn_bf16_supported": (C.c_int, [C.POINTER(Shape)]),
+    "gatmi_project_bf16_supported": (C.c_int, [C.POINTER(Shape)]),
+    "gatmi_project_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_project_fwd_bf16": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_project_bwd_bf16": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
     "gatmi_attn_bwd_workspace_bytes_bf16": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_attn_bwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1,0 +1,493 @@
+// bf16 MFMA projection for layers that keep their feature rows in bf16 (gatmi_attn.feat_bf16):
+//   forward    hp16 = bf16(x W^T)               gatmi_project_fwd_bf16
+//   backward   d_x  = (d_h + d_a_dst att_dst) W      d_W = (d_h + d_a_dst att_dst)^T x
+// Stands for `self.lin(x)` inside GATConv.forward and its autograd backward
+// (/root/reference/gat/model.py:40,43,46,54) with bf16 operands and
+// f32 accumulation (v_mfma_f32_32x32x16_bf16) -- BASELINE.json's "MFMA GEMM (bf16/fp32)".
+//
+// With bf16 MFMA these products stop being compute-bound (321 GFLOP of a 256 x 256 layer on 2.45 M
+// rows: 0.13 ms at the dense bf16 rate against 2 ms in f32): they are streaming passes over the
+// tall operand, and are built as such.
+//  * gemm_bf16_kres_kernel: the small operand (<= 256 x 256 weights, bf16, row = output column,
+//    k contiguous) lives in LDS for the life of a block; a wave owns 32-row tiles of the tall
+//    operand and takes its A fragments STRAIGHT from global memory -- lane (r, half) needs
+//    A[row r][16 s + 8 half .. + 7], eight consecutive floats of its own row -- four steps ahead,
+//    converts them to bf16 in registers and multiplies against ds_read_b128 fragments of the
+//    weights.  No A staging, no barrier in the loop.
+//  * dw_bf16_kernel: d_W contracts over the ROWS, so both operands are read as coalesced dwords
+//    (lane (r, half) supplies d_h[n + 8 half + j][32 w + r] and x[n + 8 half + j][32 t + r]),
+//    wave w of a 9-wave block owns channels 32 w .. 32 w + 31 against all of x's columns; the
+//    ninth wave multiplies d_a_dst instead, which yields the rank-H correction
+//    corr[h][f] = sum_n d_a_dst[n,h] x[n,f] of the deferred destination-logit term:
+//    d_W[c][f] += att_dst[c] corr[head(c)][f] in the finaliser.
+#include "attn_device.h"
+#include "common.h"
+
+namespace gatmi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4v &a, const f32x4v &b) {
+    u32x4 r;
+    r[0] = pack_bf16(a[0], a[1]);
+    r[1] = pack_bf16(a[2], a[3]);
+    r[2] = pack_bf16(b[0], b[1]);
+    r[3] = pack_bf16(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// Weight image for the K-resident kernel: img[n][k] bf16, n < NnP = round_up(Nn, 32),
+// k < Kp = round_up(K, 16), zero padded.  transpose == 0: src[n * ld + k] (lin.weight as it is,
+// rows = output channels, head-padded through `C`/`Cp`); transpose == 1: src[k * ld + n] (the
+// same weight read the other way round, for d_x = d_h W: n = input feature, k = padded channel).
+__global__ void weight_image_kernel(const float *src, int ld, int Nn, int K, int NnP, int Kp,
+                                    int transpose, int C, int Cp, uint16_t *img) {
+    const int total = NnP * (Kp / 2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / (Kp / 2), k = (i % (Kp / 2)) * 2;
+        float v[2];
+        for (int u = 0; u < 2; ++u) {
+            const int kk = k + u;
+            float val = 0.f;
+            if (!transpose) {                   // n = padded output channel, k = input feature
+                const int head = n / Cp, c = n % Cp;
+                if (n < Nn && c < C && kk < K) val = src[(size_t)(head * C + c) * ld + kk];
+            } else {                            // n = input feature, k = padded output channel
+                const int head = kk / Cp, c = kk % Cp;
+                if (n < Nn && kk < K && c < C) val = src[(size_t)(head * C + c) * ld + n];
+            }
+            v[u] = val;
+        }
+        reinterpret_cast<uint32_t *>(img)[i] = pack_bf16(v[0], v[1]);
+    }
+}
+
+// att_p[Dp]: att_dst in the head-padded layout (zeros in the padding)
+__global__ void pad_att_kernel(const float *att, int H, int C, int Cp, float *att_p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H * Cp) att_p[i] = (i % Cp) < C ? att[(i / Cp) * C + i % Cp] : 0.f;
+}
+
+constexpr int kKresThreads = 512;
+constexpr int kKresPad = 8;          // bf16 elements of padding per image row (16 bytes)
+constexpr int kPF = 4;               // A fragments in flight per lane (k-steps ahead)
+
+// C[M, Nn] = (A + fix)[M, K] * img^T.   A: f32 row-major (lda, rows 16-byte aligned, K % 4 == 0).
+// OUT_BF16: C is a bf16 table with row stride ldc elements, all NnP columns written (the pad
+// columns are zero because the image's pad rows are); else f32, columns < Nn.
+// FIX: A[m][k] += da_dst[m * H + k / Cp] * att_p[k]  (Cp % 8 == 0).
+template <int NT, bool OUT_BF16, bool FIX>
+__global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
+    const float *__restrict__ A, int lda, const uint16_t *__restrict__ img, void *__restrict__ Cout,
+    int ldc, long long M, int Nn, int K, int Kp, const float *__restrict__ da_dst,
+    const float *__restrict__ att_p, int H, int Cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int SB = (Kp + kKresPad) * 2;                       // image row stride in bytes
+    float *attl = reinterpret_cast<float *>(smem + (size_t)NT * 32 * SB);   // [Kp] (FIX)
+    {   // fill the image: 16-byte pieces, rows of Kp / 8 pieces
+        const int ppr = Kp / 8, total = NT * 32 * ppr;
+        for (int i = threadIdx.x; i < total; i += kKresThreads) {
+            const int n = i / ppr, q = i % ppr;
+            *reinterpret_cast<u32x4 *>(smem + (size_t)n * SB + q * 16) =
+                *reinterpret_cast<const u32x4 *>(img + (size_t)n * Kp + q * 8);
+        }
+        if (FIX)
+            for (int i = threadIdx.x; i < Kp; i += kKresThreads) attl[i] = i < K ? att_p[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int S = Kp / 16;
+    const long long tiles = (M + 31) / 32;
+    const unsigned char *b_lane = smem + (size_t)r * SB + half * 16;
+    for (long long tile = (long long)blockIdx.x * (kKresThreads / 64) + wave; tile < tiles;
+         tile += (long long)gridDim.x * (kKresThreads / 64)) {
+        const long long m0 = tile * 32;
+        const long long row = min(m0 + r, M - 1);             // rows past the end repeat the last one
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+        f32x4v ra[kPF][2];
+        float rd[kPF];
+        auto fetch = [&](int u, int s) {
+            const int k = s * 16 + half * 8;
+            // a step past K (Kp > K) reads clamped addresses; its values are zeroed below
+            const int kc = min(k, K - 8 >= 0 ? K - 8 : 0);
+            const float *p = A + (size_t)row * lda + kc;
+            ra[u][0] = *reinterpret_cast<const f32x4v *>(p);
+            ra[u][1] = *reinterpret_cast<const f32x4v *>(p + 4);
+            if (FIX) rd[u] = da_dst[(size_t)row * H + min(k, K - 1) / Cp];
+        };
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) fetch(u, min(u, S - 1));
+        for (int s0 = 0; s0 < S; s0 += kPF) {
+#pragma unroll
+            for (int u = 0; u < kPF; ++u) {
+                const int s = s0 + u;
+                if (s < S) {
+                    f32x4v a0 = ra[u][0], a1 = ra[u][1];
+                    const int k = s * 16 + half * 8;
+                    if (FIX) {
+                        const f32x4v t0 = *reinterpret_cast<const f32x4v *>(attl + k);
+                        const f32x4v t1 = *reinterpret_cast<const f32x4v *>(attl + k + 4);
+                        a0 += rd[u] * t0;
+                        a1 += rd[u] * t1;
+                    }
+                    if (k + 8 > K) {                          // the ragged last step of K % 16 != 0
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // the clamped load started at K - 8: shift is not needed for K % 8 == 0,
+                            // the only ragged case (K % 16 == 8): this half lies wholly past K
+                            a0[j] = 0.f;
+                            a1[j] = 0.f;
+                        }
+                    }
+                    const bf16x8 af = pack8(a0, a1);
+                    if (s + kPF < S) fetch(u, s + kPF);
+                    u32x4 bv[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bv[nt] = *reinterpret_cast<const u32x4 *>(b_lane + (size_t)nt * 32 * SB + s * 32);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            af, __builtin_bit_cast(bf16x8, bv[nt]), acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        // C/D layout: column = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 half
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cn = nt * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long cm = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
+                if (cm < M) {
+                    if (OUT_BF16) {
+                        const uint32_t pk = pack_bf16(acc[nt][q], 0.f);
+                        static_cast<uint16_t *>(Cout)[(size_t)cm * ldc + cn] = (uint16_t)pk;
+                    } else if (cn < Nn) {
+                        static_cast<float *>(Cout)[(size_t)cm * ldc + cn] = acc[nt][q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// a_dst[n, h] = <hp16[n, h, :], att_p[h, :]> from the bf16 table (the values the edge kernels see)
+__global__ __launch_bounds__(256) void row_dots_bf16_kernel(const uint16_t *hp16, const float *att_p,
+                                                            long long n, int H, int Cp, float *a_dst) {
+    const int lph = Cp >> 2;                                   // 4-channel slots per head
+    const long long total = n * H;
+    const int lane = threadIdx.x & 63;
+    // one (node, head) per group of `gl` lanes, gl = next_pow2(lph) <= 64
+    int gl = 1;
+    while (gl < lph) gl <<= 1;
+    const int gpw = 64 / gl, sub = lane & (gl - 1), gi = lane / gl;
+    const long long waves = (long long)gridDim.x * 4;
+    for (long long base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * gpw; base < total;
+         base += waves * gpw) {
+        const long long grp = base + gi;
+        float p = 0.f;
+        if (grp < total && sub < lph) {
+            const int head = (int)(grp % H);
+            const uint2 raw = *reinterpret_cast<const uint2 *>(hp16 + grp * Cp + sub * 4);
+            p = dot4(widen(bf16x4{raw.x, raw.y}), ld4(att_p + head * Cp + sub * 4));
+        }
+        for (int o = 1; o < gl; o <<= 1) p += __shfl_xor(p, o, 64);
+        if (grp < total && sub == 0) a_dst[grp] = p;
+    }
+}
+
+// ---- d_W ------------------------------------------------------------------------------------
+constexpr int kDwWaves = 9;          // 8 channel tiles + the d_a_dst tile
+// part[block][(8 * 32 + 32)][Fp32]: rows 32 w + i of wave w < 8: partial d_W^T... see finaliser
+template <int NJ>
+__global__ __launch_bounds__(kDwWaves * 64, 1) void dw_bf16_kernel(
+    const float *__restrict__ dh, int Dp, const float *__restrict__ x, int F,
+    const float *__restrict__ da_dst, int H, long long n_rows, long long rows_per_block,
+    int ldp /* round_up(F, 32) */, float *__restrict__ part /* [gridDim.x][9 * 32][ldp] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const long long n_beg = (long long)blockIdx.x * rows_per_block;
+    const long long n_end = min(n_rows, n_beg + rows_per_block);
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    const int f0 = blockIdx.y * NJ * 32;                       // this block's feature columns
+    const bool corr = wave == kDwWaves - 1;
+    const int ca = corr ? min(r, H - 1) : min(wave * 32 + r, Dp - 1);      // A column of this lane
+    const bool a_ok = corr ? r < H : wave * 32 + r < Dp;
+    const float *abase = corr ? da_dst : dh;
+    const int astride = corr ? H : Dp;
+    if (wave * 32 < Dp || corr) {
+        for (long long n0 = n_beg; n0 < n_end; n0 += 16) {
+            float av[8];
+            float bv[NJ][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long long nn = n0 + 8 * half + j;
+                const long long nc = min(nn, n_end - 1);
+                const float live = (nn < n_end) ? 1.f : 0.f;
+                av[j] = a_ok ? abase[(size_t)nc * astride + ca] * live : 0.f;
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) {
+                    const int f = f0 + t * 32 + r;
+                    bv[t][j] = f < F ? x[(size_t)nc * F + f] : 0.f;
+                }
+            }
+            u32x4 ap;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ap[j] = pack_bf16(av[2 * j], av[2 * j + 1]);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, ap);
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                u32x4 bp;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bp[j] = pack_bf16(bv[t][2 * j], bv[t][2 * j + 1]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bp),
+                                                                 acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float *dst = part + ((size_t)blockIdx.x * kDwWaves + wave) * 32 * ldp + f0;
+#pragma unroll
+    for (int t = 0; t < NJ; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (f0 + t * 32 < ldp) dst[(size_t)row * ldp + t * 32 + r] = acc[t][q];
+        }
+}
+
+// d_W[h * C + c][f] = sum_blocks part[b][hc_p][f] + att_p[hc_p] * sum_blocks corr[b][h][f]
+__global__ __launch_bounds__(256) void dw_bf16_final_kernel(const float *part, int nblocks, int NJ32,
+                                                            const float *att_p, int H, int C, int Cp,
+                                                            int F, int use_corr, float *dW) {
+    const int f = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int rg = threadIdx.x >> 5;                            // 8 row groups
+    const int Dp = H * Cp;
+    const size_t bstride = (size_t)kDwWaves * 32 * NJ32;
+    for (int cp = blockIdx.y * 8 + rg; cp < Dp; cp += gridDim.y * 8) {
+        const int head = cp / Cp, c = cp % Cp;
+        if (c >= C || f >= F) continue;
+        float s = 0.f, sc = 0.f;
+        const float *p = part + (size_t)cp * NJ32 + f;
+        const float *pc = part + ((size_t)(kDwWaves - 1) * 32 + head) * NJ32 + f;
+        for (int b = 0; b < nblocks; ++b) {
+            s += p[b * bstride];
+            if (use_corr) sc += pc[b * bstride];
+        }
+        dW[(size_t)(head * C + c) * F + f] = s + (use_corr ? att_p[cp] * sc : 0.f);
+    }
+}
+
+static int kres_nt(int NnP) { return NnP / 32; }
+
+template <bool OUT_BF16, bool FIX>
+static int launch_kres_bf16(int NT, const float *A, int lda, const uint16_t *img, void *C, int ldc,
+                            long long M, int Nn, int K, int Kp, const float *da_dst,
+                            const float *att_p, int H, int Cp, hipStream_t st) {
+    const size_t lds = (size_t)NT * 32 * (Kp + kKresPad) * 2 + (FIX ? (size_t)Kp * 4 : 0);
+    GATMI_REQUIRE(lds <= 160 * 1024, "bf16 projection: %d x %d weights do not fit LDS", NT * 32, Kp);
+    const long long tiles = (M + 31) / 32;
+    const int per = kKresThreads / 64;
+    long long blocks = (tiles + per - 1) / per;
+    const int cus = device_cus();
+    if (blocks > cus) blocks = cus;
+    if (blocks < 1) blocks = 1;
+#define GATMI_KRES_BF16(NTV)                                                                         \
+    case NTV: {                                                                                      \
+        auto kern = gemm_bf16_kres_kernel<NTV, OUT_BF16, FIX>;                                       \
+        GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kKresThreads), lds, st, A, lda, img, C, \
+                           ldc, M, Nn, K, Kp, da_dst, att_p, H, Cp);                                 \
+        break;                                                                                       \
+    }
+    switch (NT) {
+        GATMI_KRES_BF16(1)
+        GATMI_KRES_BF16(2)
+        GATMI_KRES_BF16(3)
+        GATMI_KRES_BF16(4)
+        GATMI_KRES_BF16(5)
+        GATMI_KRES_BF16(6)
+        GATMI_KRES_BF16(7)
+        GATMI_KRES_BF16(8)
+        default:
+            GATMI_REQUIRE(false, "bf16 projection: more than 256 output columns");
+    }
+#undef GATMI_KRES_BF16
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+struct Bf16Geo {
+    int Cp, Dp, DpP, Fp16, Fp32;   // DpP = round_up(Dp, 32), Fp16 = round_up(F, 16), Fp32 = round_up(F, 32)
+};
+static Bf16Geo bf16_geo(const gatmi_shape &s) {
+    Bf16Geo g;
+    g.Cp = round_up4(s.channels);
+    g.Dp = s.heads * g.Cp;
+    g.DpP = (g.Dp + 31) / 32 * 32;
+    g.Fp16 = (s.in_features + 15) / 16 * 16;
+    g.Fp32 = (s.in_features + 31) / 32 * 32;
+    return g;
+}
+static int dw_blocks(long long n) {
+    long long b = (n + 2047) / 2048;        // at least 2048 rows per block
+    const int cus = device_cus();
+    if (b > cus) b = cus;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace gatmi
+
+using namespace gatmi;
+
+extern "C" int gatmi_project_bf16_supported(const gatmi_shape *s) {
+    if (!s || s->heads < 1 || s->channels < 1 || s->in_features < 1) return 0;
+    const Bf16Geo g = bf16_geo(*s);
+    // operand rows 16-byte aligned and whole 8-element halves (F % 8 == 0), heads that do not
+    // straddle an 8-wide k group (Cp % 8 == 0), both weight images within LDS, <= 256 columns
+    if (s->in_features % 8 || g.Cp % 8 || g.DpP > 256 || g.Fp32 > 256) return 0;
+    const size_t fwd = (size_t)g.DpP * (g.Fp16 + kKresPad) * 2;
+    const size_t bwd = (size_t)g.Fp32 * (g.DpP + kKresPad) * 2 + (size_t)g.DpP * 4;
+    return fwd <= 160 * 1024 && bwd <= 160 * 1024 && gatmi_attn_bf16_supported(s);
+}
+
+extern "C" size_t gatmi_project_bf16_workspace_bytes(const gatmi_shape *s) {
+    if (!s) return 0;
+    const Bf16Geo g = bf16_geo(*s);
+    const size_t img = align_up((size_t)256 * 256 * 2);
+    const size_t part = align_up((size_t)dw_blocks(s->num_nodes) * kDwWaves * 32 * g.Fp32 * 4);
+    return img + align_up((size_t)g.DpP * 4) + part + 256;
+}
+
+// x [N, F] f32, weight [H*C, F] f32, att_dst [H*C] -> hp16 [N, Dp] bf16 (head-padded), a_dst [N, H]
+// (taken from the ROUNDED rows: the values the attention kernels recompute a_src from).
+extern "C" int gatmi_project_fwd_bf16(const gatmi_shape *s, const float *x, const float *weight,
+                                      const float *att_dst, void *hp16, float *a_dst, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    GATMI_REQUIRE(s && x && weight && att_dst && hp16 && a_dst && ws, "null argument");
+    GATMI_REQUIRE(gatmi_project_bf16_supported(s), "bf16 projection does not cover F=%d H=%d C=%d",
+                  s->in_features, s->heads, s->channels);
+    GATMI_REQUIRE(ws_bytes >= gatmi_project_bf16_workspace_bytes(s), "workspace too small");
+    const Bf16Geo g = bf16_geo(*s);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(ws);
+    uint16_t *img = cv.take<uint16_t>((size_t)256 * 256);
+    float *att_p = cv.take<float>(g.DpP);
+    const long long N = s->num_nodes;
+    if (N == 0) return GATMI_OK;
+    const int F = s->in_features;
+    {
+        ProfScope ps("proj16_prep", st);
+        hipLaunchKernelGGL(weight_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
+                           g.Fp16, 0, s->channels, g.Cp, img);
+        hipLaunchKernelGGL(pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst,
+                           s->heads, s->channels, g.Cp, att_p);
+        GATMI_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps("proj16_fwd_gemm", st);
+        // the table's row stride is Dp; the kernel writes DpP >= Dp columns only when DpP == Dp
+        GATMI_REQUIRE(g.DpP == g.Dp, "bf16 projection: H * round_up(C, 4) = %d must be a multiple of 32", g.Dp);
+        if (int e = launch_kres_bf16<true, false>(kres_nt(g.DpP), x, F, img, hp16, g.Dp, N, g.Dp, F,
+                                                  g.Fp16, nullptr, nullptr, s->heads, g.Cp, st))
+            return e;
+    }
+    {
+        ProfScope ps("proj16_row_dots", st);
+        const long long groups = N * s->heads;
+        long long blocks = (groups + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(row_dots_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const uint16_t *>(hp16), att_p, N, s->heads, g.Cp, a_dst);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}
+
+// d_hp [N, Dp] f32 (as gatmi_attn_bwd leaves it), d_a_dst [N, H] or NULL with att_dst [H*C]:
+//   d_weight [H*C, F] = (d_hp + d_a_dst att_dst)^T x,   d_x [N, F] = (d_hp + d_a_dst att_dst) W
+// (d_x NULL: skipped).  bf16 operands, f32 accumulation.
+extern "C" int gatmi_project_bwd_bf16(const gatmi_shape *s, const float *x, const float *weight,
+                                      const float *d_hp, const float *d_a_dst, const float *att_dst,
+                                      float *d_weight, float *d_x, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    GATMI_REQUIRE(s && x && weight && d_hp && d_weight && ws, "null argument");
+    GATMI_REQUIRE(gatmi_project_bf16_supported(s), "bf16 projection does not cover F=%d H=%d C=%d",
+                  s->in_features, s->heads, s->channels);
+    GATMI_REQUIRE(!d_a_dst || att_dst, "d_a_dst needs att_dst");
+    GATMI_REQUIRE(ws_bytes >= gatmi_project_bf16_workspace_bytes(s), "workspace too small");
+    const Bf16Geo g = bf16_geo(*s);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(ws);
+    uint16_t *img = cv.take<uint16_t>((size_t)256 * 256);
+    float *att_p = cv.take<float>(g.DpP);
+    const long long N = s->num_nodes;
+    const int F = s->in_features, H = s->heads;
+    const int nblocks = dw_blocks(N);
+    float *part = cv.take<float>((size_t)nblocks * kDwWaves * 32 * g.Fp32);
+    GATMI_REQUIRE(g.DpP == g.Dp, "bf16 projection: H * round_up(C, 4) = %d must be a multiple of 32", g.Dp);
+    if (N == 0) {
+        GATMI_HIP(hipMemsetAsync(d_weight, 0, (size_t)H * s->channels * F * 4, st));
+        return GATMI_OK;
+    }
+    {
+        ProfScope ps("proj16_prep", st);
+        if (d_x)
+            hipLaunchKernelGGL(weight_image_kernel, dim3(64), dim3(256), 0, st, weight, F, F, g.Dp,
+                               g.Fp32, g.DpP, 1, s->channels, g.Cp, img);
+        if (d_a_dst)
+            hipLaunchKernelGGL(pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst, H,
+                               s->channels, g.Cp, att_p);
+        GATMI_HIP(hipGetLastError());
+    }
+    if (d_x) {
+        ProfScope ps("proj16_bwd_x_gemm", st);
+        const int NT = g.Fp32 / 32;
+        int e;
+        if (d_a_dst)
+            e = launch_kres_bf16<false, true>(NT, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.DpP, d_a_dst,
+                                              att_p, H, g.Cp, st);
+        else
+            e = launch_kres_bf16<false, false>(NT, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.DpP, nullptr,
+                                               nullptr, H, g.Cp, st);
+        if (e) return e;
+    }
+    {
+        ProfScope ps("proj16_bwd_w_gemm", st);
+        const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
+        const int tiles = g.Fp32 / 32;
+        const int NJ = tiles < 4 ? tiles : 4;          // feature tiles per wave (64 accumulator registers)
+        const int gy = (tiles + NJ - 1) / NJ;
+        const float *dad = d_a_dst ? d_a_dst : d_hp;   // wave 8 multiplies something harmless when unused
+#define GATMI_DW_BF16(NJV)                                                                           \
+    case NJV:                                                                                        \
+        hipLaunchKernelGGL(dw_bf16_kernel<NJV>, dim3(nblocks, gy), dim3(kDwWaves * 64), 0, st, d_hp,  \
+                           g.Dp, x, F, dad, d_a_dst ? H : 1, N, rpb, g.Fp32, part);                  \
+        break;
+        switch (NJ) {
+            GATMI_DW_BF16(1)
+            GATMI_DW_BF16(2)
+            GATMI_DW_BF16(3)
+            GATMI_DW_BF16(4)
+        }
+#undef GATMI_DW_BF16
+        GATMI_HIP(hipGetLastError());
+        hipLaunchKernelGGL(dw_bf16_final_kernel, dim3(g.Fp32 / 32, 16), dim3(256), 0, st, part,
+                           nblocks, g.Fp32, att_p, H, s->channels, g.Cp, F, d_a_dst ? 1 : 0, d_weight);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}

@@ -29,7 +29,10 @@ class _GATConvFn(torch.autograd.Function):
         att_d = att_dst.contiguous().view(-1)
         bias_c = None if bias is None else bias.contiguous()
         need_grad = any(ctx.needs_input_grad[:5])
-        hp, a_dst = ops.project_fwd(x, weight, att_d, cfg.heads, cfg.channels)
+        if cfg.feat_bf16:
+            hp, a_dst = ops.project_fwd_bf16(x, weight, att_d, cfg.heads, cfg.channels)
+        else:
+            hp, a_dst = ops.project_fwd(x, weight, att_d, cfg.heads, cfg.channels)
         out, lse = ops.attn_fwd(layout, cfg, f, hp, a_dst, att_s, att_d, bias_c, need_grad)
         if need_grad:
             ctx.save_for_backward(x, weight, att_s, att_d, bias_c, hp, a_dst, out, lse)
@@ -43,8 +46,8 @@ class _GATConvFn(torch.autograd.Function):
         d_hp, d_as, d_ad, d_b, d_a_dst = ops.attn_bwd(
             layout, cfg, x.size(1), hp, a_dst, att_s, att_d, bias_c, out, lse,
             grad_out.contiguous(), defer_dst_term=True)
-        d_w, d_x = ops.project_bwd(x, weight, d_hp, cfg.heads, cfg.channels,
-                                   ctx.needs_input_grad[0], d_a_dst, att_d)
+        bwd = ops.project_bwd_bf16 if cfg.feat_bf16 else ops.project_bwd
+        d_w, d_x = bwd(x, weight, d_hp, cfg.heads, cfg.channels, ctx.needs_input_grad[0], d_a_dst, att_d)
         return d_x, d_w, d_as.view(ctx.att_shape), d_ad.view(ctx.att_shape), d_b, None, None
 
 
@@ -93,7 +96,8 @@ class GATConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
                  negative_slope: float = 0.2, dropout: float = 0.0, add_self_loops: bool = True,
                  bias: bool = True, seg_len: int = DEFAULT_SEG_LEN,
-                 input_aggregation: Optional[bool] = None, stream: Optional[bool] = None):
+                 input_aggregation: Optional[bool] = None, stream: Optional[bool] = None,
+                 feature_dtype: Optional[torch.dtype] = None):
         super().__init__()
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
@@ -105,6 +109,13 @@ class GATConv(nn.Module):
         # input-side aggregation forward: None = by table size, True/False force the LDS-DMA
         # streaming kernel / the register pipeline (tests, A/B runs)
         self.stream = stream
+        # torch.bfloat16: on the projected-row path keep the projected rows as a bf16 table and run
+        # the projection on the bf16 matrix cores (f32 accumulation, f32 softmax and sums; the
+        # tolerance is stated separately: tests/test_gpu_bf16.py).  Shapes the bf16 kernels do not
+        # cover (ops.project_bf16_supported) and the input-side path run in f32 as before.
+        if feature_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError(f"feature_dtype must be None, torch.float32 or torch.bfloat16, got {feature_dtype}")
+        self.feature_dtype = feature_dtype
         self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
         self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
@@ -150,6 +161,8 @@ class GATConv(nn.Module):
                 layout.num_edges / max(layout.num_dst, 1))
         elif use_inagg and x_grad:
             raise RuntimeError("input_aggregation=True cannot produce a gradient for x")
+        cfg.feat_bf16 = (not use_inagg and self.feature_dtype == torch.bfloat16 and
+                         ops.project_bf16_supported(self.in_channels, self.heads, self.out_channels))
         fn = _GATConvInAggFn if use_inagg else _GATConvFn
         out = fn.apply(x, self.lin.weight, self.att_src, self.att_dst, fused_bias, layout, cfg)
         if not self.concat:

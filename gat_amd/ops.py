@@ -88,6 +88,47 @@ def project_bwd(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channels: i
     return d_w, d_x
 
 
+def project_bf16_supported(in_features: int, heads: int, channels: int) -> bool:
+    """True when the bf16 projection + bf16 feature table cover this layer (gatmi_project_bf16_supported)."""
+    shape = _lib.Shape(0, in_features, heads, channels)
+    return bool(_lib.lib().gatmi_project_bf16_supported(C.byref(shape)))
+
+
+def project_fwd_bf16(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int
+                     ) -> Tuple[Tensor, Tensor]:
+    """bf16 MFMA projection: the bfloat16 feature table [N, H*Cp] and a_dst [N, H] (f32)."""
+    lib, dev = _lib.lib(), x.device
+    n, f = x.shape
+    shape = _lib.Shape(n, f, heads, channels)
+    with torch.cuda.device(dev):
+        hp16 = torch.empty(n, heads * padded_channels(channels), dtype=torch.bfloat16, device=dev)
+        a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
+        ws = _ws(lib.gatmi_project_bf16_workspace_bytes(C.byref(shape)), dev)
+        _lib.check(lib.gatmi_project_fwd_bf16(C.byref(shape), x.data_ptr(), weight.data_ptr(),
+                                              att_dst.data_ptr(), hp16.data_ptr(), a_dst.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "gatmi_project_fwd_bf16")
+    return hp16, a_dst
+
+
+def project_bwd_bf16(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channels: int,
+                     need_dx: bool, d_a_dst: Optional[Tensor] = None, att_dst: Optional[Tensor] = None
+                     ) -> Tuple[Tensor, Optional[Tensor]]:
+    """d_weight, d_x of the projection on the bf16 matrix cores (operands rounded, f32 sums)."""
+    lib, dev = _lib.lib(), x.device
+    n, f = x.shape
+    shape = _lib.Shape(n, f, heads, channels)
+    with torch.cuda.device(dev):
+        d_w = torch.empty_like(weight)
+        d_x = torch.empty_like(x) if need_dx else None
+        ws = _ws(lib.gatmi_project_bf16_workspace_bytes(C.byref(shape)), dev)
+        _lib.check(lib.gatmi_project_bwd_bf16(C.byref(shape), x.data_ptr(), weight.data_ptr(),
+                                              d_hp.data_ptr(), _ptr(d_a_dst), _ptr(att_dst),
+                                              d_w.data_ptr(), _ptr(d_x), ws.data_ptr(), ws.numel(),
+                                              _stream(dev)), "gatmi_project_bwd_bf16")
+    return d_w, d_x
+
+
 def attn_fwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor, a_dst: Tensor,
              att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], need_lse: bool
              ) -> Tuple[Tensor, Optional[Tensor]]:

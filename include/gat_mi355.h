@@ -216,6 +216,21 @@ int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
 int gatmi_attn_bf16_supported(const gatmi_shape *s);
 size_t gatmi_attn_bwd_workspace_bytes_bf16(const gatmi_graph *g, const gatmi_shape *s);
 
+/* The projection of such a layer on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, f32
+ * accumulation): x, weight, d_hp stay float32 in memory and are rounded to bf16 on their way into
+ * the MFMA; the forward writes the bf16 table hp16 [N, Dp] and a_dst [N, H] taken from the ROUNDED
+ * rows.  Same arguments as gatmi_project_fwd / gatmi_project_bwd otherwise.  Covered shapes
+ * (gatmi_project_bf16_supported): F % 8 == 0, round_up(C, 4) % 8 == 0, H * round_up(C, 4) a multiple
+ * of 32, both <= 256, and gatmi_attn_bf16_supported. */
+int gatmi_project_bf16_supported(const gatmi_shape *s);
+size_t gatmi_project_bf16_workspace_bytes(const gatmi_shape *s);
+int gatmi_project_fwd_bf16(const gatmi_shape *s, const float *x, const float *weight,
+                           const float *att_dst, void *hp16, float *a_dst, void *ws, size_t ws_bytes,
+                           void *stream);
+int gatmi_project_bwd_bf16(const gatmi_shape *s, const float *x, const float *weight,
+                           const float *d_hp, const float *d_a_dst, const float *att_dst,
+                           float *d_weight, float *d_x, void *ws, size_t ws_bytes, void *stream);
+
 /* d_hp[i, h, :] += d_a_dst[i, h] * att_dst[h, :] for i < s->num_nodes (rows of one shard). */
 int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float *d_a_dst,
                        const float *att_dst, void *stream);

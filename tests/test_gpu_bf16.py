@@ -103,6 +103,97 @@ def test_attention_kernels_on_a_bf16_table(cuda, kind, n, f, h, c, p):
                          f32_out, f32_g)
 
 
+@pytest.mark.parametrize("n,f,h,c", [(4099, 256, 4, 64), (3000, 240, 8, 32), (1000, 64, 8, 8 * 4), (5001, 24, 4, 40),
+                                     (33, 8, 8, 32), (2500, 136, 2, 128), (1, 16, 4, 64)])
+def test_bf16_projection_gemms(cuda, n, f, h, c):
+    """gatmi_project_fwd_bf16 / gatmi_project_bwd_bf16 through the C ABI against f64 products of
+    the bf16-ROUNDED operands (what the MFMA multiplies), and, looser, of the unrounded ones."""
+    from gat_amd import ops
+    assert ops.project_bf16_supported(f, h, c)
+    g = torch.Generator().manual_seed(n + f)
+    x = torch.randn(n, f, generator=g)
+    w = torch.randn(h * c, f, generator=g) / f ** 0.5
+    att = torch.randn(h * c, generator=g)
+    r = lambda t: t.to(torch.bfloat16).double()
+    xd, wd, ad = x.to(cuda), w.to(cuda), att.to(cuda)
+    hp16, a_dst = ops.project_fwd_bf16(xd, wd, ad, h, c)
+    assert hp16.dtype == torch.bfloat16 and tuple(hp16.shape) == (n, h * c)
+    href = r(x) @ r(w).t()
+    # one bf16 rounding of an f32-accumulated sum: half an ulp = 2^-9 of the value, plus the sum's own noise
+    got = hp16.double().cpu()
+    assert float(((got - href).abs() - href.abs() * 2.0 ** -8).max()) <= 1e-5 * float(href.abs().max())
+    close(a_dst, (got.view(n, h, c) * att.double().view(1, h, c)).sum(-1).float(), "a_dst")
+    dh = torch.randn(n, h * c, generator=g)
+    da = torch.randn(n, h, generator=g)
+    for with_term in (False, True):
+        full = dh.double() + (da.double().unsqueeze(-1) * att.double().view(1, h, c)).reshape(n, h * c) \
+            if with_term else dh.double()
+        dw, dx = ops.project_bwd_bf16(xd, wd, dh.to(cuda), h, c, True,
+                                      da.to(cuda) if with_term else None, ad if with_term else None)
+        fr = full.float().to(torch.bfloat16).double()             # the kernel rounds d_h + term, once
+        close(dx, (fr @ r(w)).float(), "d_x" + (" + term" if with_term else ""))
+        if not with_term:
+            close(dw, (fr.t() @ r(x)).float(), "d_weight")
+        else:   # d_W adds the term as a rank-H correction of separately rounded factors: the bf16 tolerance
+            assert rel_l2(dw, full.t() @ x.double()) <= 1e-2
+        assert rel_l2(dx, full @ w.double()) <= 1e-2 and rel_l2(dw, full.t() @ x.double()) <= 1e-2
+    dw, none = ops.project_bwd_bf16(xd, wd, dh.to(cuda), h, c, False)
+    assert none is None
+    close(dw, (r(dh).t() @ r(x)).float(), "d_weight (no d_x)")
+
+
+@pytest.mark.parametrize("kind", ["powerlaw", "knn5"])
+@pytest.mark.parametrize("n,f,h,c,p", [(3001, 256, 4, 64, 0.0), (3001, 256, 4, 64, 0.4), (2049, 240, 8, 32, 0.3),
+                                       (1200, 64, 2, 128, 0.0)])
+def test_layer_in_bf16_mode(cuda, kind, n, f, h, c, p):
+    """GATConv(feature_dtype=torch.bfloat16) with x carrying a gradient (a hidden layer): bf16
+    projection, bf16 table, f32 everything else.  Bar (1): the oracle with the same rounding points
+    (operands of the projection, the stored rows, the gradient at the aggregate); the backward
+    GEMMs round d_h once more, which the oracle does not model -- hence 1e-2 in L2 for the
+    gradients there and the f32 bar for the forward.  Bar (2): the stated bf16 tolerance."""
+    from gat_amd import GATConv, _lib
+    ei = graph(kind, n, seed=n + h)
+    x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c, seed=n)
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p, seed=1) if p > 0 else None
+    kw = dict(dropout=p, mask=mask, training=p > 0)
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, bf16_tables=True,
+                                              bf16_matmul=True, **kw)
+    f32_out, f32_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, **kw)
+    conv = GATConv(f, c, heads=h, dropout=p, feature_dtype=torch.bfloat16).to(cuda).train(p > 0)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
+    conv.injected_mask = mask
+    xd = x.to(cuda).requires_grad_(True)
+    _lib.prof_read(); _lib.prof_enable(True)
+    out = conv(xd, ei.to(cuda))
+    out.backward(go.to(cuda))
+    torch.cuda.synchronize(); _lib.prof_enable(False)
+    tags = {t for t, _ in _lib.prof_read()}
+    assert {"proj16_fwd_gemm", "proj16_bwd_w_gemm", "proj16_bwd_x_gemm", "attn_fwd"} <= tags, tags
+    grads = dict(x=xd.grad, weight=conv.lin.weight.grad, att_src=conv.att_src.grad,
+                 att_dst=conv.att_dst.grad, bias=conv.bias.grad)
+    assert rel(out, ref_out) <= 2e-3          # a table entry within an ulp of a rounding boundary may round the other way
+    assert rel_l2(out, ref_out) <= 2e-4
+    for k in ("x", "weight"):
+        assert rel_l2(grads[k], ref_g[k]) <= 1e-2, (k, rel_l2(grads[k], ref_g[k]))
+    close(grads["bias"], ref_g["bias"], "d_bias")
+    check_bf16_tolerance(out, grads, f32_out, f32_g)
+
+
+def test_bf16_mode_falls_back_to_f32_where_not_covered(cuda):
+    from gat_amd import GATConv, _lib, ops
+    assert not ops.project_bf16_supported(1433, 8, 8) and not ops.project_bf16_supported(25, 8, 30)
+    ei, n = cases.knn_graph(n=300, f=6, seed=2)
+    conv = GATConv(25, 30, heads=8, feature_dtype=torch.bfloat16).to(cuda).eval()
+    x = torch.randn(n, 25, device=cuda, requires_grad=True)
+    _lib.prof_read(); _lib.prof_enable(True)
+    conv(x, ei.to(cuda)).sum().backward()
+    torch.cuda.synchronize(); _lib.prof_enable(False)
+    tags = {t for t, _ in _lib.prof_read()}
+    assert "proj_fwd_gemm" in tags and "proj16_fwd_gemm" not in tags
+
+
 def test_bf16_tables_are_refused_for_narrow_rows(cuda):
     from gat_amd import _lib, ops
     from gat_amd.graph import build_graph
