@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-exchange-h", action="store_true",
                     help="N>1: skip the second timed region (exchange=h, the north_star's all-gather of "
                          "projected features) that is reported next to --exchange auto")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: projected rows kept as a bf16 table, projection on the bf16 matrix cores "
+                         "(layers on the projected-row path only; tolerance: tests/test_gpu_bf16.py)")
     ap.add_argument("--no-extra-layers", action="store_true",
                     help="N=1: skip the hidden-layer and model-sum measurements (products only)")
     args = ap.parse_args()
@@ -156,7 +159,7 @@ def main():
     res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (head["ms_per_step"] * 1e-3),
            "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
            "config": {"workload": head["text"], "nodes": n, "edges": ep, "in_features": f, "heads": h,
                       "channels": c, "parallelism": "single GPU", "path": path,
                       "graph_layout_build_s": round(head["layout_s"], 4)},
@@ -179,6 +182,26 @@ def main():
                          "avg_ms": round(hid["avg"][hdom], 4), "algorithmic_bytes": hid["kb"][hdom],
                          "survey_8d_bytes": survey_8d_bytes(n, ep, hid["h"], hid["c"])},
             "kernels": kernel_table(hid["avg"], hid["kb"])}
+        if args.dtype == "f32":
+            # the same hidden layer with bf16 feature rows and the bf16 projection: reported NEXT TO
+            # the f32 figures, never in their place (tolerance stated in tests/test_gpu_bf16.py)
+            h16 = measure_layer(hidden_name, args, dev, dtype="bf16")
+            if h16["dtype"] == "bf16":
+                d16 = max(h16["kb"], key=lambda k: h16["avg"].get(k, 0.0))
+                a16 = h16["kb"][d16] / (h16["avg"][d16] * 1e-3) / 1e9
+                res["hidden_layer_bf16"] = {
+                    "dtype": "bf16", "workload": h16["text"], "ms_per_step": round(h16["ms_per_step"], 4),
+                    "value": ep / (h16["ms_per_step"] * 1e-3), "unit": "edges/s",
+                    "roofline": {"bound": "hbm", "kernel": d16, "achieved": round(a16, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a16 / HBM_PEAK_GBS, 4),
+                                 "avg_ms": round(h16["avg"][d16], 4), "algorithmic_bytes": h16["kb"][d16]},
+                    "kernels": kernel_table(h16["avg"], h16["kb"]),
+                    "tolerance": "out 1e-2 max-norm, d_x / d_W 5e-2 relative L2 against the f32 oracle "
+                                 "(tests/test_gpu_bf16.py)"}
+                res["model_sum_bf16_hidden"] = {
+                    "ms_per_step": round(head["ms_per_step"] + 2 * h16["ms_per_step"], 4),
+                    "edges_per_s_per_layer": 3 * ep / ((head["ms_per_step"] + 2 * h16["ms_per_step"]) * 1e-3),
+                    "note": "f32 input layer + two bf16 hidden layers"}
         total_ms = head["ms_per_step"] + 2 * hid["ms_per_step"]
         res["model_sum"] = {
             "layers": [f"{f}->{h}x{c} (input, no d_x)", f"{hid['f']}->{hid['h']}x{hid['c']} (hidden, d_x)",
@@ -204,7 +227,7 @@ def survey_8d_bytes(n, ep, h, c):
     return {"fwd": fwd, "bwd": bwd, "total": fwd + bwd}
 
 
-def measure_layer(workload, args, dev):
+def measure_layer(workload, args, dev, dtype=None):
     """Time `args.steps` forward+backward steps of one GAT layer on the named synthetic graph
     (inputs resident in HBM, layout built beforehand) and collect the library's per-kernel HIP-event
     timings over the same steps."""
@@ -219,9 +242,10 @@ def measure_layer(workload, args, dev):
     hidden = workload.endswith("_hidden")   # a hidden layer: x has a gradient, d_x is part of the step
     x.requires_grad_(hidden)
     torch.manual_seed(args.seed)
+    dtype = dtype or args.dtype
     conv = GATConv(f, c, heads=h, dropout=args.dropout,
-                   input_aggregation={"auto": None, "on": True, "off": False}[args.input_aggregation]
-                   ).to(dev).train()
+                   input_aggregation={"auto": None, "on": True, "off": False}[args.input_aggregation],
+                   feature_dtype=torch.bfloat16 if dtype == "bf16" else None).to(dev).train()
 
     torch.cuda.synchronize()
     t0 = time.time()
@@ -255,7 +279,9 @@ def measure_layer(workload, args, dev):
     text = (f"{workload}-shaped synthetic graph: {n} nodes, {ei.size(1)} edges ({ep} after self-loop "
             f"normalisation), one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
             f"attention dropout {args.dropout} (train mode)")
-    res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, kb=kernel_bytes(n, ep, h, d, f),
+    ran_bf16 = "proj16_fwd_gemm" in avg
+    res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, dtype="bf16" if ran_bf16 else "f32",
+               kb=kernel_bytes(n, ep, h, d, f, feat_bytes=2 if ran_bf16 else 4),
                ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text)
     del conv, x, go, layout, ei
     from gat_amd.graph import clear_graph_cache

@@ -206,87 +206,123 @@ __global__ __launch_bounds__(256) void row_dots_bf16_kernel(const uint16_t *hp16
 }
 
 // ---- d_W ------------------------------------------------------------------------------------
-constexpr int kDwWaves = 9;          // 8 channel tiles + the d_a_dst tile
-// part[block][(8 * 32 + 32)][Fp32]: rows 32 w + i of wave w < 8: partial d_W^T... see finaliser
-template <int NJ>
+// d_W contracts over the ROWS (nodes), so an MFMA operand -- 8 consecutive k of one row/column per
+// lane -- is 8 NODES of one channel (A) or one feature (B): strided in memory.  The contraction
+// index can be permuted freely and so can the assignment of channels/features to tiles: lane r
+// of a wave takes, per node, ONE float2 of d_h (channels c0 + 2r, c0 + 2r + 1 -> A tiles 0, 1) and
+// ONE float4 of x (features f0 + 4r .. 4r + 3 -> B tiles 0..3), i.e. tile t holds the features
+// congruent to t mod 4.  16 vector loads feed 8 MFMAs (a 64 x 128 block of d_W^T per wave); the 8
+// waves of a block -- 4 channel groups x 2 feature groups -- cover 256 x 256 for the block's rows.
+// FIX: A = d_h[n][c] + d_a_dst[n][head(c)] att_p[c] (both channels of a lane lie in one head).
+// Operands are packed to bf16 as soon as they land and the next rows' loads are issued before
+// the MFMAs of this step.
+constexpr int kDwWaves = 8;
+template <bool FIX>
 __global__ __launch_bounds__(kDwWaves * 64, 1) void dw_bf16_kernel(
     const float *__restrict__ dh, int Dp, const float *__restrict__ x, int F,
-    const float *__restrict__ da_dst, int H, long long n_rows, long long rows_per_block,
-    int ldp /* round_up(F, 32) */, float *__restrict__ part /* [gridDim.x][9 * 32][ldp] */) {
+    const float *__restrict__ da_dst, const float *__restrict__ att_p, int H, int Cp,
+    long long n_rows, long long rows_per_block, int ldp /* round_up(F, 32) */,
+    float *__restrict__ part /* [gridDim.x][Dp][ldp] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
     const long long n_beg = (long long)blockIdx.x * rows_per_block;
     const long long n_end = min(n_rows, n_beg + rows_per_block);
-    f32x16 acc[NJ];
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    for (int cg = wave & 3; cg * 64 < Dp; cg += 4)
+        for (int fg = wave >> 2; fg * 128 < ldp; fg += 2) {
+            const int c0 = cg * 64, f0 = fg * 128;
+            const int c = min(c0 + 2 * r, Dp - 2);
+            const bool c_ok = c0 + 2 * r < Dp;                  // Dp is even
+            const int fx = min(f0 + 4 * r, F - 4);
+            const bool f_ok = f0 + 4 * r < F;                   // F % 4 == 0
+            const f32x2v attc = FIX ? *reinterpret_cast<const f32x2v *>(att_p + c) : f32x2v{0.f, 0.f};
+            const int head = c / Cp;
+            f32x16 acc[2][4];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-    const int f0 = blockIdx.y * NJ * 32;                       // this block's feature columns
-    const bool corr = wave == kDwWaves - 1;
-    const int ca = corr ? min(r, H - 1) : min(wave * 32 + r, Dp - 1);      // A column of this lane
-    const bool a_ok = corr ? r < H : wave * 32 + r < Dp;
-    const float *abase = corr ? da_dst : dh;
-    const int astride = corr ? H : Dp;
-    if (wave * 32 < Dp || corr) {
-        for (long long n0 = n_beg; n0 < n_end; n0 += 16) {
-            float av[8];
-            float bv[NJ][8];
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const long long nn = n0 + 8 * half + j;
-                const long long nc = min(nn, n_end - 1);
-                const float live = (nn < n_end) ? 1.f : 0.f;
-                av[j] = a_ok ? abase[(size_t)nc * astride + ca] * live : 0.f;
+                    for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
+            f32x2v ra[8];
+            f32x4v rb[8];
+            float rd[8];
+            auto fetch = [&](long long n0) {
 #pragma unroll
-                for (int t = 0; t < NJ; ++t) {
-                    const int f = f0 + t * 32 + r;
-                    bv[t][j] = f < F ? x[(size_t)nc * F + f] : 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const long long nc = min(n0 + 8 * half + j, n_end - 1);
+                    ra[j] = *reinterpret_cast<const f32x2v *>(dh + (size_t)nc * Dp + c);
+                    rb[j] = *reinterpret_cast<const f32x4v *>(x + (size_t)nc * F + fx);
+                    if (FIX) rd[j] = da_dst[(size_t)nc * H + head];
                 }
+            };
+            if (n_beg < n_end) fetch(n_beg);
+            for (long long n0 = n_beg; n0 < n_end; n0 += 16) {
+                u32x4 ap[2], bp[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float a[2][2];
+                    f32x4v bq[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = 2 * jj + u;
+                        const bool live = n0 + 8 * half + j < n_end;
+                        f32x2v v = ra[j];
+                        if (FIX) v += rd[j] * attc;
+                        a[0][u] = (live && c_ok) ? v[0] : 0.f;
+                        a[1][u] = (live && c_ok) ? v[1] : 0.f;
+                        bq[u] = (live && f_ok) ? rb[j] : f32x4v{0.f, 0.f, 0.f, 0.f};
+                    }
+                    ap[0][jj] = pack_bf16(a[0][0], a[0][1]);
+                    ap[1][jj] = pack_bf16(a[1][0], a[1][1]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bp[t][jj] = pack_bf16(bq[0][t], bq[1][t]);
+                }
+                if (n0 + 16 < n_end) fetch(n0 + 16);           // in flight during the MFMAs
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, ap[i]), __builtin_bit_cast(bf16x8, bp[t]),
+                            acc[i][t], 0, 0, 0);
             }
-            u32x4 ap;
+            // C row i <-> channel c0 + 2 i + tile, C column r <-> feature f0 + 4 r + t
+            float *dst = part + (size_t)blockIdx.x * Dp * ldp;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ap[j] = pack_bf16(av[2 * j], av[2 * j + 1]);
-            const bf16x8 af = __builtin_bit_cast(bf16x8, ap);
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int t = 0; t < NJ; ++t) {
-                u32x4 bp;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bp[j] = pack_bf16(bv[t][2 * j], bv[t][2 * j + 1]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bp),
-                                                                 acc[t], 0, 0, 0);
-            }
-        }
-    }
-    float *dst = part + ((size_t)blockIdx.x * kDwWaves + wave) * 32 * ldp + f0;
-#pragma unroll
-    for (int t = 0; t < NJ; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
-            if (f0 + t * 32 < ldp) dst[(size_t)row * ldp + t * 32 + r] = acc[t][q];
+                for (int q = 0; q < 16; ++q) {
+                    const int ch = c0 + 2 * ((q & 3) + 8 * (q >> 2) + 4 * half) + i;
+                    if (ch < Dp && f0 + 4 * r < ldp) {
+                        f32x4v o = {acc[i][0][q], acc[i][1][q], acc[i][2][q], acc[i][3][q]};
+                        *reinterpret_cast<f32x4v *>(dst + (size_t)ch * ldp + f0 + 4 * r) = o;
+                    }
+                }
         }
 }
 
-// d_W[h * C + c][f] = sum_blocks part[b][hc_p][f] + att_p[hc_p] * sum_blocks corr[b][h][f]
-__global__ __launch_bounds__(256) void dw_bf16_final_kernel(const float *part, int nblocks, int NJ32,
-                                                            const float *att_p, int H, int C, int Cp,
-                                                            int F, int use_corr, float *dW) {
+// d_W[h * C + c][f] = sum over blocks of part[b][h * Cp + c][f]   (fixed order)
+__global__ __launch_bounds__(256) void dw_bf16_final_kernel(const float *part, int nblocks, int ldp,
+                                                            int H, int C, int Cp, int F, float *dW) {
     const int f = blockIdx.x * 32 + (threadIdx.x & 31);
     const int rg = threadIdx.x >> 5;                            // 8 row groups
     const int Dp = H * Cp;
-    const size_t bstride = (size_t)kDwWaves * 32 * NJ32;
+    const size_t bstride = (size_t)Dp * ldp;
     for (int cp = blockIdx.y * 8 + rg; cp < Dp; cp += gridDim.y * 8) {
         const int head = cp / Cp, c = cp % Cp;
         if (c >= C || f >= F) continue;
-        float s = 0.f, sc = 0.f;
-        const float *p = part + (size_t)cp * NJ32 + f;
-        const float *pc = part + ((size_t)(kDwWaves - 1) * 32 + head) * NJ32 + f;
-        for (int b = 0; b < nblocks; ++b) {
-            s += p[b * bstride];
-            if (use_corr) sc += pc[b * bstride];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float *p = part + (size_t)cp * ldp + f;
+        int b = 0;
+        for (; b + 3 < nblocks; b += 4) {
+            s0 += p[(size_t)b * bstride];
+            s1 += p[(size_t)(b + 1) * bstride];
+            s2 += p[(size_t)(b + 2) * bstride];
+            s3 += p[(size_t)(b + 3) * bstride];
         }
-        dW[(size_t)(head * C + c) * F + f] = s + (use_corr ? att_p[cp] * sc : 0.f);
+        for (; b < nblocks; ++b) s0 += p[(size_t)b * bstride];
+        dW[(size_t)(head * C + c) * F + f] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -368,7 +404,7 @@ extern "C" size_t gatmi_project_bf16_workspace_bytes(const gatmi_shape *s) {
     if (!s) return 0;
     const Bf16Geo g = bf16_geo(*s);
     const size_t img = align_up((size_t)256 * 256 * 2);
-    const size_t part = align_up((size_t)dw_blocks(s->num_nodes) * kDwWaves * 32 * g.Fp32 * 4);
+    const size_t part = align_up((size_t)dw_blocks(s->num_nodes) * g.DpP * g.Fp32 * 4);
     return img + align_up((size_t)g.DpP * 4) + part + 256;
 }
 
@@ -437,7 +473,7 @@ extern "C" int gatmi_project_bwd_bf16(const gatmi_shape *s, const float *x, cons
     const long long N = s->num_nodes;
     const int F = s->in_features, H = s->heads;
     const int nblocks = dw_blocks(N);
-    float *part = cv.take<float>((size_t)nblocks * kDwWaves * 32 * g.Fp32);
+    float *part = cv.take<float>((size_t)nblocks * g.DpP * g.Fp32);
     GATMI_REQUIRE(g.DpP == g.Dp, "bf16 projection: H * round_up(C, 4) = %d must be a multiple of 32", g.Dp);
     if (N == 0) {
         GATMI_HIP(hipMemsetAsync(d_weight, 0, (size_t)H * s->channels * F * 4, st));
@@ -468,25 +504,15 @@ extern "C" int gatmi_project_bwd_bf16(const gatmi_shape *s, const float *x, cons
     {
         ProfScope ps("proj16_bwd_w_gemm", st);
         const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
-        const int tiles = g.Fp32 / 32;
-        const int NJ = tiles < 4 ? tiles : 4;          // feature tiles per wave (64 accumulator registers)
-        const int gy = (tiles + NJ - 1) / NJ;
-        const float *dad = d_a_dst ? d_a_dst : d_hp;   // wave 8 multiplies something harmless when unused
-#define GATMI_DW_BF16(NJV)                                                                           \
-    case NJV:                                                                                        \
-        hipLaunchKernelGGL(dw_bf16_kernel<NJV>, dim3(nblocks, gy), dim3(kDwWaves * 64), 0, st, d_hp,  \
-                           g.Dp, x, F, dad, d_a_dst ? H : 1, N, rpb, g.Fp32, part);                  \
-        break;
-        switch (NJ) {
-            GATMI_DW_BF16(1)
-            GATMI_DW_BF16(2)
-            GATMI_DW_BF16(3)
-            GATMI_DW_BF16(4)
-        }
-#undef GATMI_DW_BF16
+        if (d_a_dst)
+            hipLaunchKernelGGL(dw_bf16_kernel<true>, dim3(nblocks), dim3(kDwWaves * 64), 0, st, d_hp,
+                               g.Dp, x, F, d_a_dst, att_p, H, g.Cp, N, rpb, g.Fp32, part);
+        else
+            hipLaunchKernelGGL(dw_bf16_kernel<false>, dim3(nblocks), dim3(kDwWaves * 64), 0, st, d_hp,
+                               g.Dp, x, F, d_a_dst, att_p, H, g.Cp, N, rpb, g.Fp32, part);
         GATMI_HIP(hipGetLastError());
         hipLaunchKernelGGL(dw_bf16_final_kernel, dim3(g.Fp32 / 32, 16), dim3(256), 0, st, part,
-                           nblocks, g.Fp32, att_p, H, s->channels, g.Cp, F, d_a_dst ? 1 : 0, d_weight);
+                           nblocks, g.Fp32, H, s->channels, g.Cp, F, d_weight);
         GATMI_HIP(hipGetLastError());
     }
     return GATMI_OK;

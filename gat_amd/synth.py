@@ -62,7 +62,7 @@ def workload_graph(name: str, seed: int = 0, device="cpu", scale: float = 1.0):
     return powerlaw_graph(n, e, int(dmax * max(scale, 0.05)) if dmax else 0, seed, device), n, f, h, c
 
 
-def kernel_bytes(n, e, h, d, f):
+def kernel_bytes(n, e, h, d, f, feat_bytes=4):
     """Algorithmic bytes per launch of the two heavy edge kernels (fp32 values, int32
     indices).  Forward is SURVEY.md 8d's B_fwd.  The backward gathers
     features once instead of SURVEY 8d's twice: one pass over the transposed CSR reads, per
@@ -71,8 +71,10 @@ def kernel_bytes(n, e, h, d, f):
     fp = (f + 3) // 4 * 4
     fs = fp + (h + 3) // 4 * 4        # packed source row: x | a_src
     return {
-        "attn_fwd": e * (4 * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
-        "attn_bwd_edge": e * (4 * d + 16 * h + 8 + 4 * h) + n * (8 * d + 4 * h),
+        # feat_bytes = 2: bf16 feature tables -- the gathered rows (h in the forward, the bf16 copy
+        # of grad_out in the backward) and the row-local h are half as wide; out, d_h, a_src stay f32
+        "attn_fwd": e * (feat_bytes * d + 4 * h + 4) + n * (4 * d + 12 * h + 4),
+        "attn_bwd_edge": e * (feat_bytes * d + 16 * h + 8 + 4 * h) + n * ((4 + feat_bytes) * d + 4 * h),
         # input-side aggregation (gat_amd/csrc/inagg.hip): an edge moves a packed source row
         # x | a_src (4 Fs bytes) and its col index; a node reads rowptr and a_dst, writes Z [H, Fp]
         # and lse (forward); reads its own packed row, q and Z [H, Fp], a_dst and lse (backward;
