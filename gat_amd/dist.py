@@ -236,7 +236,13 @@ class HipBackend:
 
     def project_fwd(self, x, w, att_d, cfg):
         from . import ops
+        if cfg.feat_bf16:      # bf16 table: half the bytes on the wire of exchange "h" and in the gathers
+            return ops.project_fwd_bf16(x, w, att_d, cfg.heads, cfg.channels)
         return ops.project_fwd(x, w, att_d, cfg.heads, cfg.channels)
+
+    def bf16_supported(self, f, cfg):
+        from . import ops
+        return ops.project_bf16_supported(f, cfg.heads, cfg.channels)
 
     def attn_fwd(self, layout, cfg, f, hp_full, a_dst, att_s, att_d, bias, need_lse):
         from . import ops
@@ -253,7 +259,8 @@ class HipBackend:
 
     def project_bwd(self, x, w, d_hp, cfg, need_dx):
         from . import ops
-        return ops.project_bwd(x, w, d_hp.contiguous(), cfg.heads, cfg.channels, need_dx)
+        bwd = ops.project_bwd_bf16 if cfg.feat_bf16 else ops.project_bwd
+        return bwd(x, w, d_hp.contiguous(), cfg.heads, cfg.channels, need_dx)
 
     # input-side aggregation (x without gradient, F < H*Cp)
     def inagg_supported(self, f, cfg):
@@ -399,12 +406,16 @@ class PartitionedGATConv(nn.Module):
     all-reduced, so every rank steps identically."""
 
     def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, dropout=0.0,
-                 bias=True, backend=None, group=None, exchange="auto", balance="edges"):
+                 bias=True, backend=None, group=None, exchange="auto", balance="edges",
+                 feature_dtype=None):
         super().__init__()
         from .layer import _glorot_
         if balance not in ("edges", "nodes"):
             raise ValueError(f"balance must be 'edges' or 'nodes', got {balance!r}")
         self.balance = balance      # destination ranges of equal in-edge count / equal node count
+        # torch.bfloat16: exchange "h" projects into a bf16 table, all-gathers THAT (half the xGMI
+        # volume, SURVEY.md 8e) and gathers bf16 rows; d_h travels back in f32.  Other modes: f32.
+        self.feature_dtype = feature_dtype
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.negative_slope, self.dropout = negative_slope, dropout
         self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
@@ -452,6 +463,8 @@ class PartitionedGATConv(nn.Module):
         cfg = AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
                          mask_mode, seed, None)
         mode = self.resolve_exchange(x_local, cfg)
+        cfg.feat_bf16 = (mode == "h" and self.feature_dtype == torch.bfloat16
+                         and getattr(self.backend, "bf16_supported", lambda f, c: False)(self.in_channels, cfg))
         if mode in ("xs", "as"):
             return _PartitionedInAggFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
                                              self.bias, part, layout, cfg, self.backend,
@@ -625,7 +638,9 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     x.requires_grad_(hidden)
     torch.manual_seed(args.seed)
     conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout, balance=balance,
-                              exchange=getattr(args, "exchange", "auto")).to(dev).train()
+                              exchange=getattr(args, "exchange", "auto"),
+                              feature_dtype=torch.bfloat16 if getattr(args, "dtype", "f32") == "bf16" else None
+                              ).to(dev).train()
     torch.cuda.synchronize()
     t0 = time.time()
     layout = conv.layout_for(ei, part)
@@ -679,7 +694,8 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
         res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
                "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None,
+               "dtype": "bf16" if "proj16_fwd_gemm" in avg else "f32", "data": "synthetic",
                "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
                                       f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
                                       f"layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "

@@ -71,7 +71,8 @@ def print_epoch_stats(epoch, seconds, tr, va, cm):
 
 class GAT(nn.Module):
     def __init__(self, optimizer, num_features, num_classes, weight_decay=1e-3, dropout=0.7,
-                 hidden_dim=16, epochs=30, lr=0.005, patience=3, device=None, verbose=True):
+                 hidden_dim=16, epochs=30, lr=0.005, patience=3, device=None, verbose=True,
+                 feature_dtype=None):
         super().__init__()
         self.epochs, self.patience, self.num_classes = epochs, patience, num_classes
         self.verbose = verbose
@@ -79,11 +80,16 @@ class GAT(nn.Module):
         # elu -> bn -> dropout between the layers as one fused op (gat_amd/glue.py) instead of
         # three stock ones; same modules, same state_dict
         self.fused_glue = True
-        self.conv1 = GATConv(num_features, hidden_dim, heads=8, dropout=dropout)
+        # feature_dtype=torch.bfloat16 (not in the reference; default None = f32 everywhere): the
+        # layers on the projected-row path whose shape the bf16 kernels cover keep their projected
+        # rows in bf16 (gat_amd/layer.py); with the reference's widths that is conv2 when
+        # hidden_dim is a multiple of 8.  The parity claims of this package are for the default.
+        kw = dict(dropout=dropout, feature_dtype=feature_dtype)
+        self.conv1 = GATConv(num_features, hidden_dim, heads=8, **kw)
         self.bn1 = nn.BatchNorm1d(hidden_dim * 8)
-        self.conv2 = GATConv(hidden_dim * 8, hidden_dim, heads=8, dropout=dropout)
+        self.conv2 = GATConv(hidden_dim * 8, hidden_dim, heads=8, **kw)
         self.bn2 = nn.BatchNorm1d(hidden_dim * 8)
-        self.conv3 = GATConv(hidden_dim * 8, num_classes, heads=1, concat=True, dropout=dropout)
+        self.conv3 = GATConv(hidden_dim * 8, num_classes, heads=1, concat=True, **kw)
         self.dropout = nn.Dropout(p=dropout)
         self.device = torch.device(device) if device is not None else default_device()
         self.to(self.device)

@@ -178,6 +178,49 @@ def test_layer_in_bf16_mode(cuda, kind, n, f, h, c, p):
     check_bf16_tolerance(out, grads, f32_out, f32_g)
 
 
+@pytest.mark.parametrize("world,balance", [(2, "edges"), (3, "nodes")])
+def test_partitioned_layer_with_bf16_exchange(cuda, world, balance):
+    """exchange "h" with a bf16 table (what PartitionedGATConv(feature_dtype=torch.bfloat16) runs per
+    rank): every rank projects its rows into bf16, the table is their concatenation (the all-gather,
+    half the bytes), d_h comes back in f32 -- one process plays all ranks."""
+    from gat_amd import ops, synth
+    from gat_amd.dist import HipBackend, local_edges, make_partition
+    n, f, h, c = 2500, 64, 4, 64
+    ei = synth.powerlaw_graph(n, 8 * n, 500, seed=5)
+    x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c, seed=6)
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, bf16_tables=True, bf16_matmul=True)
+    be = HipBackend()
+    cfg = ops.AttnConfig(h, c)
+    cfg.feat_bf16 = True
+    xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
+    asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
+    parts = [make_partition(ei, n, world, r, balance) for r in range(world)]
+    shards = []
+    for p in parts:
+        hp, a_dst = be.project_fwd(xd[p.lo:p.hi].contiguous(), wd, add_, cfg)
+        assert hp.dtype == torch.bfloat16
+        pad = hp.new_zeros(p.block, hp.size(1)); pad[:p.n_local] = hp
+        shards.append((pad, a_dst))
+    hp_full = torch.cat([s_[0] for s_ in shards])
+    d_hp_sum, outs, d_adst = None, [], []
+    for p, (_, a_dst) in zip(parts, shards):
+        lay = be.build_layout(local_edges(ei.to(cuda), p), p)
+        out, lse = be.attn_fwd(lay, cfg, f, hp_full, a_dst, asd, add_, bd, True)
+        outs.append(out)
+        r_ = be.attn_bwd(lay, cfg, f, hp_full, a_dst, asd, add_, bd, out, lse, god[p.lo:p.hi].contiguous())
+        d_hp_sum = r_[0] if d_hp_sum is None else d_hp_sum + r_[0]
+        d_adst.append(r_[4])
+    out = torch.cat(outs)
+    assert rel(out, ref_out) <= 2e-3 and rel_l2(out, ref_out) <= 2e-4
+    d_w, d_x = 0, []
+    for p, dd in zip(parts, d_adst):
+        blk = d_hp_sum[p.plo:p.phi].contiguous()
+        be.add_dst_term(blk, dd, add_, cfg)
+        dw, dx = be.project_bwd(xd[p.lo:p.hi].contiguous(), wd, blk, cfg, True)
+        d_w = d_w + dw; d_x.append(dx)
+    assert rel_l2(torch.cat(d_x), ref_g["x"]) <= 1e-2 and rel_l2(d_w, ref_g["weight"]) <= 1e-2
+
+
 def test_bf16_mode_falls_back_to_f32_where_not_covered(cuda):
     from gat_amd import GATConv, _lib, ops
     assert not ops.project_bf16_supported(1433, 8, 8) and not ops.project_bf16_supported(25, 8, 30)
