@@ -12,7 +12,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GATMI_LIB") or os.path.join(_PKG, "libgat_mi355.so")  # override: kernel A/B builds
 
-MASK_NONE, MASK_BYTES, MASK_HASH = 0, 1, 2
+MASK_NONE, MASK_BYTES, MASK_HASH, MASK_HASH_DEV = 0, 1, 2, 3
 
 _i32p = C.POINTER(C.c_int32)
 
@@ -59,7 +59,7 @@ class InAgg(C.Structure):
 class Glue(C.Structure):
     _fields_ = [("rows", C.c_int64), ("cols", C.c_int32), ("training", C.c_int32),
                 ("eps", C.c_float), ("momentum", C.c_float), ("dropout_p", C.c_float),
-                ("_pad", C.c_int32), ("seed", C.c_uint64), ("gamma", C.c_void_p),
+                ("seed_on_device", C.c_int32), ("seed", C.c_uint64), ("gamma", C.c_void_p),
                 ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
 
 

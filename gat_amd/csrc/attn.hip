@@ -772,8 +772,9 @@ static int check_attn(const gatmi_graph *g, const gatmi_attn *a) {
                   g->dst_offset + g->num_dst, g->num_src);
     GATMI_REQUIRE(g->seg_len >= 64 && g->seg_len % 64 == 0, "seg_len %d must be a multiple of 64",
                   g->seg_len);
-    GATMI_REQUIRE(a->mask_mode >= 0 && a->mask_mode <= 2, "bad mask_mode %d", a->mask_mode);
-    GATMI_REQUIRE(a->mask_mode != GATMI_MASK_BYTES || a->mask, "mask_mode BYTES needs a mask");
+    GATMI_REQUIRE(a->mask_mode >= 0 && a->mask_mode <= 3, "bad mask_mode %d", a->mask_mode);
+    GATMI_REQUIRE((a->mask_mode != GATMI_MASK_BYTES && a->mask_mode != GATMI_MASK_HASH_DEV) || a->mask,
+                  "mask_mode BYTES / HASH_DEV needs `mask` (the keep flags / the device seed)");
     GATMI_REQUIRE(a->dropout_p >= 0.f && a->dropout_p <= 1.f, "dropout_p %f outside [0,1]",
                   a->dropout_p);
     GATMI_REQUIRE(a->mask_mode == GATMI_MASK_NONE || a->shape.heads <= 32,

@@ -136,6 +136,10 @@ __device__ __forceinline__ bool keep_hash(uint32_t seed_lo, uint32_t seed_hi, ui
 __device__ __forceinline__ uint32_t keep_bits(int mode, const uint8_t *mask, uint64_t seed,
                                               uint32_t thr, long long e, int heads) {
     if (mode == 0) return 0xFFFFFFFFu;
+    if (mode == 3) {    // GATMI_MASK_HASH_DEV: the seed lives in device memory (`mask` points at it),
+        seed = *reinterpret_cast<const uint64_t *>(mask);   // so a captured graph can replay with new masks
+        mode = 2;
+    }
     uint32_t bits = 0;
     if (mode == 1) {
         const uint8_t *m = mask + e * heads;

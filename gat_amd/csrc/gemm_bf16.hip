@@ -340,11 +340,19 @@ static int launch_kres_bf16(int NT, const float *A, int lda, const uint16_t *img
     const int cus = device_cus();
     if (blocks > cus) blocks = cus;
     if (blocks < 1) blocks = 1;
+    constexpr int kMaxDev = 64;
+    int dev = 0;
+    GATMI_HIP(hipGetDevice(&dev));
+    GATMI_REQUIRE(dev >= 0 && dev < kMaxDev, "device ordinal %d", dev);
 #define GATMI_KRES_BF16(NTV)                                                                         \
     case NTV: {                                                                                      \
         auto kern = gemm_bf16_kres_kernel<NTV, OUT_BF16, FIX>;                                       \
-        GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        static size_t granted[kMaxDev] = {};   /* per device: the attribute is per device */         \
+        if (granted[dev] < lds) {                                                                    \
+            GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+            granted[dev] = lds;                                                                      \
+        }                                                                                            \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kKresThreads), lds, st, A, lda, img, C, \
                            ldc, M, Nn, K, Kp, da_dst, att_p, H, Cp);                                 \
         break;                                                                                       \

@@ -29,6 +29,7 @@ struct GlueArgs {
     int training;
     float inv_keep, inv_rows;
     uint32_t keep_thr, seed_lo, seed_hi;
+    const uint64_t *seed_ptr;  // gatmi_glue.seed_on_device: the seed is read from device memory
     const float *gamma, *beta, *mean, *rstd;   // [cols]
     const float *dsum;        // [2][cols]: d_beta, d_gamma (backward apply)
     float *partial;           // [blocks][2][nslot*4]
@@ -180,7 +181,13 @@ __global__ void glue_eval_stats_kernel(const float *running_mean, const float *r
 
 __device__ __forceinline__ float keepf(const GlueArgs &A, long long r, int c) {
     if (A.keep_thr == 0) return 1.0f;
-    return keep_hash(A.seed_lo, A.seed_hi, A.keep_thr, (uint32_t)r, (uint32_t)c) ? A.inv_keep : 0.f;
+    uint32_t lo = A.seed_lo, hi = A.seed_hi;
+    if (A.seed_ptr) {
+        const uint64_t sd = *A.seed_ptr;
+        lo = (uint32_t)sd;
+        hi = (uint32_t)(sd >> 32);
+    }
+    return keep_hash(lo, hi, A.keep_thr, (uint32_t)r, (uint32_t)c) ? A.inv_keep : 0.f;
 }
 
 __global__ __launch_bounds__(256) void glue_apply_fwd_kernel(const GlueArgs A) {
@@ -315,6 +322,7 @@ static void glue_fill(GlueArgs &A, const gatmi_glue *g) {
     A.keep_thr = drop ? (uint32_t)((double)g->dropout_p * 16777216.0) : 0u;
     A.seed_lo = (uint32_t)g->seed;
     A.seed_hi = (uint32_t)(g->seed >> 32);
+    A.seed_ptr = g->seed_on_device ? reinterpret_cast<const uint64_t *>((uintptr_t)g->seed) : nullptr;
     A.inv_rows = g->rows > 0 ? 1.0f / (float)g->rows : 0.f;
     A.gamma = g->gamma;
     A.beta = g->beta;

@@ -19,7 +19,11 @@ from . import _lib
 def _desc(rows, cols, training, eps, momentum, p, seed, gamma, beta, rmean, rvar):
     g = _lib.Glue()
     g.rows, g.cols, g.training = rows, cols, int(training)
-    g.eps, g.momentum, g.dropout_p, g.seed = float(eps), float(momentum), float(p), int(seed)
+    g.eps, g.momentum, g.dropout_p = float(eps), float(momentum), float(p)
+    if isinstance(seed, Tensor):       # a device-resident seed (HIP-graph replays): pass its address
+        g.seed_on_device, g.seed = 1, seed.data_ptr()
+    else:
+        g.seed_on_device, g.seed = 0, int(seed) & 0xFFFFFFFFFFFFFFFF
     g.gamma, g.beta = gamma.data_ptr(), beta.data_ptr()
     g.running_mean = None if rmean is None else rmean.data_ptr()
     g.running_var = None if rvar is None else rvar.data_ptr()
@@ -68,10 +72,15 @@ class _GlueFn(torch.autograd.Function):
         return gx, dg, db, None, None, None, None, None, None, None
 
 
-def elu_bn_dropout(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed: int = None) -> Tensor:
+SEED_STEP = 0x1E3779B97F4A7C15      # what a device-resident seed advances by per use (odd, < 2^63)
+
+
+def elu_bn_dropout(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed=None) -> Tensor:
     """dropout(bn(elu(x))) with `bn`'s parameters and running statistics (updated in training,
     like the module would).  `seed` fixes the dropout mask (tests); default: drawn from torch's
-    generator."""
+    generator.  `seed` may be a one-element int64 CUDA tensor: it is advanced in place on the
+    device and read by the kernels from there, so the call can be captured in a HIP graph and
+    every replay draws a new mask."""
     if not x.is_cuda:
         raise RuntimeError("gat_amd.glue runs on the GPU only (no CPU fallback)")
     if x.dim() != 2 or x.size(1) != bn.num_features:
@@ -82,7 +91,12 @@ def elu_bn_dropout(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed
         raise ValueError("elu_bn_dropout covers nn.BatchNorm1d's defaults (affine, running statistics, "
                          "momentum), as the reference constructs it at model.py:27,29")
     drop = training and p > 0.0
-    if seed is None:
+    if isinstance(seed, Tensor):
+        if drop:
+            seed.add_(SEED_STEP)
+        else:
+            seed = 0
+    elif seed is None:
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop else 0
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)

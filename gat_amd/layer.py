@@ -124,6 +124,12 @@ class GATConv(nn.Module):
         else:
             self.register_parameter("bias", None)
         self.injected_mask: Optional[Tensor] = None  # test hook, [E', H] in normalised edge order
+        # One-element int64 CUDA tensor, or None.  Set: the attention-dropout seed lives on the
+        # device -- advanced in place before every training forward, read by the kernels from
+        # there (GATMI_MASK_HASH_DEV) -- so a step captured in a HIP graph draws a new mask at
+        # every replay.  None: a fresh seed from torch's CPU generator per call (a by-value
+        # kernel argument, which a graph would freeze).
+        self.device_seed: Optional[Tensor] = None
         self.reset_parameters()
 
     def reset_parameters(self) -> None:
@@ -146,6 +152,10 @@ class GATConv(nn.Module):
         if self.training and self.dropout > 0.0:
             if self.injected_mask is not None:
                 mask_mode, mask = _lib.MASK_BYTES, layout.edge_mask_to_csr(self.injected_mask)
+            elif self.device_seed is not None:
+                from .glue import SEED_STEP
+                self.device_seed.add_(SEED_STEP)
+                mask_mode, mask = _lib.MASK_HASH_DEV, self.device_seed
             else:
                 mask_mode = _lib.MASK_HASH
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())

@@ -39,6 +39,9 @@ extern "C" {
 #define GATMI_MASK_NONE 0   /* eval mode / p = 0 */
 #define GATMI_MASK_BYTES 1  /* keep-mask given as bytes [E', H] in dst-CSR edge order */
 #define GATMI_MASK_HASH 2   /* keep-mask derived on the fly from (seed, edge, head) */
+#define GATMI_MASK_HASH_DEV 3 /* as HASH, the 64-bit seed read from device memory: `mask` points at it
+                               (8-byte aligned).  For steps captured in a HIP graph: the caller bumps
+                               the seed on the device between replays and every replay draws a new mask */
 
 const char *gatmi_last_error(void);
 int gatmi_version(void);
@@ -305,7 +308,7 @@ typedef struct gatmi_glue {
     float eps;             /* BatchNorm1d eps (1e-5)                                   */
     float momentum;        /* BatchNorm1d momentum (0.1)                               */
     float dropout_p;       /* nn.Dropout p (model.py:31), [0, 1)                       */
-    int32_t _pad;
+    int32_t seed_on_device; /* 1: `seed` holds the ADDRESS of a 64-bit seed in device memory (HIP graphs) */
     uint64_t seed;
     const float *gamma;    /* BatchNorm weight [D]                                     */
     const float *beta;     /* BatchNorm bias [D]                                       */

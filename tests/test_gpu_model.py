@@ -79,3 +79,71 @@ def test_training_mode_runs_with_dropout_and_learns(cuda, tmp_path, monkeypatch)
     assert (tmp_path / "best_model.pth").exists()
     sd = torch.load(tmp_path / "best_model.pth")
     assert "conv1.lin.weight" in sd and "conv3.att_src" in sd
+
+
+def test_device_seed_makes_a_captured_layer_step_draw_new_masks(cuda):
+    """GATMI_MASK_HASH_DEV: with `device_seed` set the layer's dropout seed is read from device
+    memory and advanced on the device, so a HIP graph of forward + backward draws a new mask at
+    every replay -- and a replay equals the eager step started from the same seed, bit for bit."""
+    from gat_amd import GATConv
+    from gat_amd.glue import SEED_STEP
+    import cases
+    ei, n = cases.knn_graph(n=600, f=6, seed=5)
+    eid = ei.to(cuda)
+    for f, h, c, grad_x in ((25, 8, 30, False), (240, 8, 30, True)):      # input-side path / projected rows
+        torch.manual_seed(3)
+        conv = GATConv(f, c, heads=h, dropout=0.4).to(cuda).train()
+        x = torch.randn(n, f, device=cuda, requires_grad=grad_x)
+        go = torch.randn(n, h * c, device=cuda)
+        conv.device_seed = torch.tensor([12345], dtype=torch.int64, device=cuda)
+
+        def step():
+            out = conv(x, eid)
+            out.backward(go)
+            return out.detach()
+
+        eager = []
+        for _ in range(3):                      # seeds 12345 + k * SEED_STEP, k = 1, 2, 3
+            conv.zero_grad(set_to_none=True)
+            eager.append((step().clone(), conv.lin.weight.grad.clone()))
+        assert not torch.equal(eager[0][0], eager[1][0])
+        conv.device_seed.fill_(12345)
+        conv.zero_grad(set_to_none=True)
+        x.grad = None
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        assert int(conv.device_seed) == 12345   # capture records, it does not run
+        for k in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert int(conv.device_seed) == 12345 + (k + 1) * SEED_STEP
+            assert torch.equal(out, eager[k][0]) and torch.equal(conv.lin.weight.grad, eager[k][1]), (f, k)
+
+
+def test_hipgraph_training_matches_eager_training(cuda, tmp_path, monkeypatch):
+    """GAT(hipgraph=True): epochs 3.. replay captured graphs of the training step and of the
+    validation forward.  Without dropout the loss curves equal the eager run's bit for bit; with
+    dropout the run trains (new masks every replay: the training loss keeps moving)."""
+    from gat_amd.model import GAT
+    monkeypatch.chdir(tmp_path)
+    X, y = synthetic_traces(1200, 25, seed=5)
+    tr = convert_to_graph(X[:900], y[:900])
+    va = convert_to_graph(X[900:], y[900:])
+    curves = []
+    for hipgraph in (False, True):
+        torch.manual_seed(2)
+        model = GAT(torch.optim.AdamW, 25, 2, weight_decay=4.8e-4, dropout=0.0, hidden_dim=30, epochs=7,
+                    lr=0.02, patience=50, device=cuda, verbose=False, hipgraph=hipgraph)
+        m = model.train_model(tr, va)
+        curves.append((m.train_loss, m.val_loss, m.val_accuracy))
+        if hipgraph:
+            assert len(model._graphs) == 2
+    assert curves[0] == curves[1]
+    torch.manual_seed(2)
+    model = GAT(torch.optim.AdamW, 25, 2, weight_decay=4.8e-4, dropout=0.425, hidden_dim=30, epochs=8,
+                lr=0.02, patience=50, device=cuda, verbose=False, hipgraph=True)
+    m = model.train_model(tr, va)
+    assert all(np.isfinite(m.train_loss)) and len(set(m.train_loss)) == 8
+    assert min(m.val_loss) < 0.52
