@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: projected rows kept as a bf16 table, projection on the bf16 matrix cores "
                          "(layers on the projected-row path only; tolerance: tests/test_gpu_bf16.py)")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="N=1: also time the same step replayed as ONE captured HIP graph (dropout seed on "
+                         "the device, GATMI_MASK_HASH_DEV) -> `hipgraph` in the line; for launch-bound graphs")
     ap.add_argument("--no-extra-layers", action="store_true",
                     help="N=1: skip the hidden-layer and model-sum measurements (products only)")
     args = ap.parse_args()
@@ -164,6 +167,11 @@ def main():
                       "channels": c, "parallelism": "single GPU", "path": path,
                       "graph_layout_build_s": round(head["layout_s"], 4)},
            "roofline": roofline, "kernels": kernel_table(avg, kb)}
+    if head["graph_ms"] is not None:
+        res["hipgraph"] = {"ms_per_step": round(head["graph_ms"], 4), "value": ep / (head["graph_ms"] * 1e-3),
+                           "unit": "edges/s", "kernel_ms_sum": round(sum(avg.values()), 4),
+                           "note": "the same forward + backward replayed as one captured HIP graph; "
+                                   "`value` above is the eager step (one host launch per kernel)"}
 
     # "report per layer and summed over the model's layers".  The headline is the
     # network's INPUT layer (x is data: no d_x, input-side aggregation).  The layers behind it take
@@ -276,13 +284,36 @@ def measure_layer(workload, args, dev, dtype=None):
     for tag, ms in _lib.prof_read():
         per.setdefault(tag, []).append(ms)
     avg = {k: sum(v) / len(v) for k, v in per.items()}
+    graph_ms = None
+    if getattr(args, "hipgraph", False):
+        conv.device_seed = torch.tensor([args.seed + 1], dtype=torch.int64, device=dev)
+        conv.zero_grad(set_to_none=True)
+        x.grad = None
+        for _ in range(2):
+            step()
+        conv.zero_grad(set_to_none=True)
+        x.grad = None
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = conv(x, ei)
+            out.backward(go)
+        for _ in range(args.warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        del graph, out
     text = (f"{workload}-shaped synthetic graph: {n} nodes, {ei.size(1)} edges ({ep} after self-loop "
             f"normalisation), one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
             f"attention dropout {args.dropout} (train mode)")
     ran_bf16 = "proj16_fwd_gemm" in avg
     res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, dtype="bf16" if ran_bf16 else "f32",
                kb=kernel_bytes(n, ep, h, d, f, feat_bytes=2 if ran_bf16 else 4),
-               ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text)
+               ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text, graph_ms=graph_ms)
     del conv, x, go, layout, ei
     from gat_amd.graph import clear_graph_cache
     clear_graph_cache()

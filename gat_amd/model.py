@@ -148,9 +148,14 @@ class GAT(nn.Module):
 
     def _scores(self, out, y, loss):
         preds = out.argmax(dim=1)
-        cm = confusion_counts(y, preds, max(self.num_classes, int(out.size(1)))).cpu()
+        k = max(self.num_classes, int(out.size(1)))
+        # confusion matrix and loss cross to the host in ONE copy (one synchronisation per call;
+        # the counts are exact in float64)
+        packed = torch.cat([confusion_counts(y, preds, k).flatten().to(torch.float64),
+                            loss.detach().to(torch.float64).view(1)]).cpu()
+        cm = packed[:-1].to(torch.int64).view(k, k)
         accuracy = float(cm.diag().sum()) / max(int(y.size(0)), 1)
-        return (float(loss), accuracy) + weighted_prf(cm), cm
+        return (float(packed[-1]), accuracy) + weighted_prf(cm), cm
 
     # -- HIP-graph replay of a step (hipgraph=True)
     def _captured_step(self, kind: str, data):

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--classes", type=int, default=40)
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--hipgraph", action="store_true", help="replay the step as a captured HIP graph")
+    ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ei, n, f, _, _ = synth.workload_graph(args.workload, 0, dev, args.scale)
@@ -28,7 +30,7 @@ def main():
     data = Data(torch.randn(n, f, generator=g, device=dev), ei,
                 torch.randint(0, args.classes, (n,), generator=g, device=dev))
     model = GAT(torch.optim.AdamW, f, args.classes, dropout=0.425, hidden_dim=args.hidden, lr=0.01,
-                device=dev, verbose=False)
+                device=dev, verbose=False, hipgraph=args.hipgraph)
     for _ in range(3):
         model.train_epoch(data)
     torch.cuda.synchronize()
@@ -37,8 +39,10 @@ def main():
         model.train_epoch(data)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.epochs * 1e3
-    print(f"{args.workload} x{args.scale}: N={n} E={ei.size(1)} hidden=8x{args.hidden}: "
-          f"train epoch {ms:.3f} ms")
+    print(f"{args.workload} x{args.scale}: N={n} E={ei.size(1)} hidden=8x{args.hidden}"
+          f"{' hipgraph' if args.hipgraph else ''}: train epoch {ms:.3f} ms", flush=True)
+    if args.no_profile:
+        return
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         for _ in range(3):
