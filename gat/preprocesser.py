@@ -1,19 +1,39 @@
-"""Stand-ins for the reference's feature engineering (/root/reference/gat/preprocesser.py:
-50-90), which is host-side pandas ETL over a CSV the reference does not ship -- out of the
-hot path.  preprocess_df() returns the prepared table,
-preprocess_X / preprocess_y split it, with the reference's names and return types."""
+"""The reference's feature engineering under its own import path
+(/root/reference/gat/preprocesser.py:50-90): preprocess_df() loads data/traces.csv (or the file
+GAT_TRACES_CSV names) and runs gat_amd/etl.py -- the reference's pipeline, vectorised.  The
+reference does not ship that CSV; when it is absent the synthetic stand-in table of
+gat_amd.trials.load_xy() is used instead and says so."""
+import os
+
+from gat_amd import etl
 from gat_amd.trials import load_xy
+
+_PREPARED = "__prepared__"      # marks the stand-in table, whose columns are final already
+
+
+def _csv_path():
+    return os.environ.get("GAT_TRACES_CSV", os.path.join("data", "traces.csv"))
 
 
 def preprocess_df():
-    X, y = load_xy()
+    path = _csv_path()
+    if os.path.exists(path):
+        import pandas as pd
+        print("Start loading data...")
+        raw = pd.read_csv(path)
+        print("Data loaded successfully.")
+        return etl.preprocess_df(raw)
+    X, y = load_xy()     # GAT_TRACES_NPZ or the synthetic stand-in: columns are final already
     df = X.copy()
     df["is_anomaly"] = y.values
+    df.attrs[_PREPARED] = True
     return df
 
 
 def preprocess_X(df):
-    return df.drop(columns=["is_anomaly"])
+    if df.attrs.get(_PREPARED):
+        return df.drop(columns=["is_anomaly"])
+    return etl.preprocess_X(df)
 
 
 def preprocess_y(df):

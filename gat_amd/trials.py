@@ -51,13 +51,20 @@ _GRAPHS = None
 
 
 def load_xy():
-    """(X, y) once per process.  data/traces.csv is not in the reference repository, so the
-    feature-engineering pipeline (out of scope) is replaced
-    by a synthetic table of the same shape unless GAT_TRACES_NPZ points at prepared arrays."""
+    """(X, y) once per process, as grid_search.py:42-49 caches them.  In this order: the reference's
+    own input, data/traces.csv (or the file GAT_TRACES_CSV names), through the reference's feature
+    engineering (gat_amd/etl.py); prepared arrays GAT_TRACES_NPZ points at; else -- the reference
+    does not ship its CSV -- a synthetic table of the same shape, announced as such."""
     global _XY
     if _XY is None:
+        csv = os.environ.get("GAT_TRACES_CSV", os.path.join("data", "traces.csv"))
         path = os.environ.get("GAT_TRACES_NPZ")
-        if path:
+        if os.path.exists(csv):
+            import pandas as pd
+            from . import etl
+            df = etl.preprocess_df(pd.read_csv(csv))
+            _XY = (etl.preprocess_X(df), etl.preprocess_y(df))
+        elif path:
             import pandas as pd
             z = np.load(path)
             _XY = (pd.DataFrame(z["X"]), pd.Series(z["y"]))
