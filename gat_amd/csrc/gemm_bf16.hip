@@ -14,12 +14,12 @@
 //    A[row r][16 s + 8 half .. + 7], eight consecutive floats of its own row -- four steps ahead,
 //    converts them to bf16 in registers and multiplies against ds_read_b128 fragments of the
 //    weights.  No A staging, no barrier in the loop.
-//  * dw_bf16_kernel: d_W contracts over the ROWS, so both operands are read as coalesced dwords
-//    (lane (r, half) supplies d_h[n + 8 half + j][32 w + r] and x[n + 8 half + j][32 t + r]),
-//    wave w of a 9-wave block owns channels 32 w .. 32 w + 31 against all of x's columns; the
-//    ninth wave multiplies d_a_dst instead, which yields the rank-H correction
-//    corr[h][f] = sum_n d_a_dst[n,h] x[n,f] of the deferred destination-logit term:
-//    d_W[c][f] += att_dst[c] corr[head(c)][f] in the finaliser.
+//  * dw_bf16_kernel: d_W contracts over the ROWS (nodes), so an MFMA operand is 8 nodes of one
+//    channel or feature -- strided in memory.  The contraction index and the assignment of
+//    channels / features to tiles are free, so a lane takes per node one float2 of d_h (two A
+//    tiles) and one float4 of x (four B tiles): 16 vector loads feed 8 MFMAs (see the kernel).
+//    The deferred destination-logit term d_h += d_a_dst att_dst is added to the A operand in
+//    registers, in both backward kernels.
 #include "attn_device.h"
 #include "common.h"
 
