@@ -182,12 +182,14 @@ def main():
         hid = measure_layer(hidden_name, args, dev)
         hdom = max(hid["kb"], key=lambda k: hid["avg"].get(k, 0.0))
         hach = hid["kb"][hdom] / (hid["avg"][hdom] * 1e-3) / 1e9
+        htraffic, htsrc = measured_traffic(args.workload, hdom + ("_bf16" if hid["dtype"] == "bf16" else ""))
         res["hidden_layer"] = {
             "workload": hid["text"], "ms_per_step": round(hid["ms_per_step"], 4),
             "value": ep / (hid["ms_per_step"] * 1e-3), "unit": "edges/s", "path": "projected rows",
             "roofline": {"bound": "hbm", "kernel": hdom, "achieved": round(hach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(hach / HBM_PEAK_GBS, 4),
                          "avg_ms": round(hid["avg"][hdom], 4), "algorithmic_bytes": hid["kb"][hdom],
+                         "traffic": htraffic, "traffic_source": htsrc,
                          "survey_8d_bytes": survey_8d_bytes(n, ep, hid["h"], hid["c"])},
             "kernels": kernel_table(hid["avg"], hid["kb"])}
         if args.dtype == "f32":
@@ -197,12 +199,14 @@ def main():
             if h16["dtype"] == "bf16":
                 d16 = max(h16["kb"], key=lambda k: h16["avg"].get(k, 0.0))
                 a16 = h16["kb"][d16] / (h16["avg"][d16] * 1e-3) / 1e9
+                t16, t16src = measured_traffic(args.workload, d16 + "_bf16")
                 res["hidden_layer_bf16"] = {
                     "dtype": "bf16", "workload": h16["text"], "ms_per_step": round(h16["ms_per_step"], 4),
                     "value": ep / (h16["ms_per_step"] * 1e-3), "unit": "edges/s",
                     "roofline": {"bound": "hbm", "kernel": d16, "achieved": round(a16, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a16 / HBM_PEAK_GBS, 4),
-                                 "avg_ms": round(h16["avg"][d16], 4), "algorithmic_bytes": h16["kb"][d16]},
+                                 "avg_ms": round(h16["avg"][d16], 4), "algorithmic_bytes": h16["kb"][d16],
+                                 "traffic": t16, "traffic_source": t16src},
                     "kernels": kernel_table(h16["avg"], h16["kb"]),
                     "tolerance": "out 1e-2 max-norm, d_x / d_W 5e-2 relative L2 against the f32 oracle "
                                  "(tests/test_gpu_bf16.py)"}

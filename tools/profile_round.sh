@@ -1,6 +1,6 @@
 # One GPU call: bench lines for every workload, rocprofv3 kernel stats and the two PMC passes
-# for the default bench command.  Writes under gpurun_out/prof_$TAG/; tools/collect_profiles.py
-# copies the summaries into profiles/.
+# for the default bench command (input layer + hidden layer f32 + hidden layer bf16).  Writes under
+# gpurun_out/prof_$TAG/; tools/collect_profiles.py copies the summaries into profiles/.
 TAG=${1:-cur}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
