@@ -83,7 +83,11 @@ struct RowArgs {
 // ---------------------------------------------------------------------------------
 template <int LPH2_T, int G, int T, class RAW>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? GATMI_U : (T == 2 ? 2 : 1);
+#ifndef GATMI_U16
+#define GATMI_U16 GATMI_U
+#endif
+    // edges per batch (two batches are in flight); bf16 rows are half as wide
+    constexpr int U = (T == 1) ? (sizeof(RAW) == 8 ? GATMI_U16 : GATMI_U) : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
     float4 att[T], acc[T];
     float adi[T], m[T], ssum[T];
@@ -366,7 +370,11 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
 
 template <int LPH2_T, int G, int T, class RAW>
 __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
-    constexpr int U = (T == 1) ? GATMI_U : (T == 2 ? 2 : 1);
+#ifndef GATMI_U16
+#define GATMI_U16 GATMI_U
+#endif
+    // edges per batch (two batches are in flight); bf16 rows are half as wide
+    constexpr int U = (T == 1) ? (sizeof(RAW) == 8 ? GATMI_U16 : GATMI_U) : (T == 2 ? 2 : 1);
     GATMI_ITEM_LOOP_BEGIN
     float4 att[T], hj[T], acc[T];
     float asj[T], das[T];
@@ -878,7 +886,6 @@ extern "C" int gatmi_attn_fwd(const gatmi_graph *g, const gatmi_attn *a, float *
 static __device__ __align__(256) unsigned char scratch[GATMI_STATIC_SCRATCH_BYTES];
 
 namespace {
-constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 void *g_scratch_ptr[kMaxDevices] = {};
 

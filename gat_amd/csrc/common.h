@@ -108,6 +108,8 @@ int launch_gemm(const GemmDesc &d, hipStream_t st);
 // tall row-major A (16-byte aligned rows, K <= 128), small B kept in LDS: see project.hip
 bool kres_covers(const GemmDesc &d);
 int launch_kres(const GemmDesc &d, hipStream_t st);
+constexpr int kMaxDevices = 64;
+int device_index(); // ordinal of the current device, for per-device caches (0 when out of range)
 int device_cus();   // CUs of the current device (256 when it cannot be queried)
 int option(const char *name, int dflt);   // gatmi_set_option / environment switch, see errors.cpp
 

@@ -340,10 +340,8 @@ static int launch_kres_bf16(int NT, const float *A, int lda, const uint16_t *img
     const int cus = device_cus();
     if (blocks > cus) blocks = cus;
     if (blocks < 1) blocks = 1;
-    constexpr int kMaxDev = 64;
-    int dev = 0;
-    GATMI_HIP(hipGetDevice(&dev));
-    GATMI_REQUIRE(dev >= 0 && dev < kMaxDev, "device ordinal %d", dev);
+    constexpr int kMaxDev = kMaxDevices;
+    const int dev = device_index();
 #define GATMI_KRES_BF16(NTV)                                                                         \
     case NTV: {                                                                                      \
         auto kern = gemm_bf16_kres_kernel<NTV, OUT_BF16, FIX>;                                       \

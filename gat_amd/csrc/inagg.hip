@@ -2162,7 +2162,10 @@ template <class K> static int resident_blocks(K kernel) {
 template <int LH_T, int T>
 static void stream_launch(InKind k, const InArgs &A, hipStream_t st) {
     if (k == IN_FWD) {
-        static const int grid = resident_blocks(inagg_fwd_stream_kernel<LH_T, T>);
+        static int grids[kMaxDevices] = {};      // per device: occupancy and CU count are the device's
+        const int di = device_index();
+        if (grids[di] == 0) grids[di] = resident_blocks(inagg_fwd_stream_kernel<LH_T, T>);
+        const int grid = grids[di];
         const int need = (A.n_chunks + 3) / 4;
         hipLaunchKernelGGL((inagg_fwd_stream_kernel<LH_T, T>), dim3(need < grid ? need : grid),
                            dim3(256), 0, st, A);

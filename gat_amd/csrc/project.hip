@@ -962,19 +962,15 @@ bool kres_covers(const GemmDesc &d) {
 template <int NT, bool SWZ>
 static void kres_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     const size_t lds = kres_dyn_lds(nf4), lds_all = kres_lds_bytes(nf4, NT);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus < 1)
-            cus = 256;
-    }
-    static size_t dyn_cap = 0;   // dynamic LDS beyond 64 KiB has to be granted per kernel
-    if (lds > dyn_cap) {
+    const int cus = device_cus();
+    // dynamic LDS beyond 64 KiB has to be granted per kernel AND per device (the attribute applies
+    // to the current device only: a process driving several GPUs needs it on each)
+    static size_t dyn_cap[kMaxDevices] = {};
+    const int di = device_index();
+    if (lds > dyn_cap[di]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kres_kernel<NT, SWZ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-            dyn_cap = lds;
+            dyn_cap[di] = lds;
     }
     const int per_cu = (int)((160 * 1024) / lds_all) < 1 ? 1 : (int)((160 * 1024) / lds_all);
     long long bx = ((long long)cus * per_cu + d.nbatch - 1) / d.nbatch;   // one resident set
@@ -986,15 +982,22 @@ static void kres_launch(const GemmDesc &d, int nf4, hipStream_t st) {
                        d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, gb);
 }
 
+int device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+
 int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
+    static int cus[kMaxDevices] = {};
+    const int di = device_index();
+    if (cus[di] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, di) != hipSuccess || c < 1)
+            c = 256;
+        cus[di] = c;
     }
-    return cus;
+    return cus[di];
 }
 
 template <int NT, int KC, bool SWZ, bool TAIL = false>
@@ -1003,11 +1006,12 @@ static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     int nbuf = (int)((160 * 1024) / (4 * tileb));
     nbuf = nbuf > 4 ? 4 : nbuf;
     const size_t lds = (size_t)4 * nbuf * tileb;
-    static size_t dyn_cap = 0;   // dynamic LDS beyond 64 KiB has to be granted per kernel
-    if (lds > dyn_cap) {
+    static size_t dyn_cap[kMaxDevices] = {};   // granted per kernel and per device (see kres_launch)
+    const int di = device_index();
+    if (lds > dyn_cap[di]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kreg_kernel<NT, KC, SWZ, TAIL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-            dyn_cap = lds;
+            dyn_cap[di] = lds;
     }
     long long bx = ((long long)device_cus() + d.nbatch - 1) / d.nbatch;   // one resident set
     const long long need = (((long long)d.M + 31) / 32 + 3) / 4;
