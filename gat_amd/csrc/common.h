@@ -113,4 +113,13 @@ int device_index(); // ordinal of the current device, for per-device caches (0 w
 int device_cus();   // CUs of the current device (256 when it cannot be queried)
 int option(const char *name, int dflt);   // gatmi_set_option / environment switch, see errors.cpp
 
+// f32-accurate projection GEMMs on the bf16 matrix cores (three-way operand split), gemm_split3.hip
+bool split3_covers(const gatmi_shape &s);
+size_t split3_workspace_bytes(const gatmi_shape &s);
+int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, float *hp, void *ws,
+                       hipStream_t st);
+int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight, const float *d_hp,
+                       const float *d_a_dst, const float *att_dst, float *d_weight, float *d_x,
+                       void *ws, hipStream_t st);
+
 }  // namespace gatmi

@@ -1,0 +1,501 @@
+// f32-accurate projection GEMMs on the bf16 matrix cores: what gatmi_project_fwd / gatmi_project_bwd
+// run for wide hidden layers (project.hip; switch GATMI_SPLIT3).  Stands for `self.lin(x)` inside
+// GATConv.forward and its autograd backward (/root/reference/gat/model.py:40,43,46,54; SURVEY.md 8a
+// rows a5, a11) in f32 -- the f32 bar of tests/test_gpu_parity.py applies, not the bf16 one.
+//
+// Every f32 operand is cut, exactly, into three bf16 pieces v = p0 + p1 + p2 (8 + 8 + 8 significand
+// bits: each residual is exact in f32 and the last one fits bf16).  The six products p_i q_j with
+// i + j <= 2 carry the f32 product to ~2^-24, so one f32 multiply-add costs six bf16 ones:
+// 6 x v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) against 8 x v_mfma_f32_32x32x2_f32 (64
+// cycles each) for the same 32 x 32 x 16 block: 192 against 512 cycles.  Measured error against an
+// fp64 product (tools/split_probe.py): at or below the f32 MFMA kernels'.
+//
+//  * split3_gemm_kernel  C[M, Nn] = (A + fix)[M, K] W^T, M tall, Nn and K <= 256.  A block of 8 waves
+//    owns 256 rows at a time and ALL columns, so every A element is fetched and cut once (lane
+//    (r, half) takes its MFMA fragment -- 8 consecutive floats of row r -- straight from global
+//    memory, two k-steps ahead).  The three pieces of W (3 x 128 KB at 256 x 256) do not fit LDS:
+//    they stream through it in chunks of 32 k (48 KB, double buffered, one barrier per chunk) from
+//    an image that stays in L2.
+//  * split3_dw_kernel    d_W^T[Dp, F] = (d_h + fix)^T x, contraction over the rows: a wave (one per
+//    SIMD, 128 x 128 outputs = 16 accumulator tiles) takes per node one float4 of d_h and one
+//    float4 of x; tile i / t holds the channels / features congruent to i / t mod 4 and the
+//    contraction index runs over 8 nodes per half.  Per-block partial sums, fixed-order reduction.
+#include "attn_device.h"
+#include "common.h"
+
+namespace gatmi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCk = 32;                   // k per chunk of the weight stream (two MFMA steps)
+constexpr int kRowB = kCk * 2 + 16;       // bytes of one (piece, column) row of a chunk in LDS: 64 + pad
+                                          // (20 dwords apart: 16 lanes' b128 reads hit 64 different banks)
+constexpr int kGemmThreads = 512, kGemmWaves = 8;
+
+// one pair of values -> bf16 pair (low half = first) and the exact residuals
+__device__ __forceinline__ uint32_t cut_pair(float &a, float &b) {
+    const uint32_t pk = pack_bf16(a, b);
+    a -= __uint_as_float(pk << 16);
+    b -= __uint_as_float(pk & 0xffff0000u);
+    return pk;
+}
+
+// Weight image, chunked along k: img[chunk][piece][n < NnP][32 k] bf16, zero padded (NnP = round_up
+// (Nn, 32), chunks = Kp / 32).  transpose == 0: src[n * ld + k], rows = output channels in the
+// head-padded layout through C / Cp (forward: n = padded channel, k = input feature);
+// transpose == 1: src[k * ld + n] (d_x = d_h W: n = input feature, k = padded channel).
+__global__ void split3_image_kernel(const float *src, int ld, int Nn, int K, int NnP, int Kp,
+                                    int transpose, int C, int Cp, uint16_t *img) {
+    const int total = NnP * (Kp / 2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / (Kp / 2), k = (i % (Kp / 2)) * 2;
+        float v[2];
+        for (int u = 0; u < 2; ++u) {
+            const int kk = k + u;
+            float val = 0.f;
+            if (!transpose) {
+                const int head = n / Cp, c = n % Cp;
+                if (n < Nn && c < C && kk < K) val = src[(size_t)(head * C + c) * ld + kk];
+            } else {
+                const int head = kk / Cp, c = kk % Cp;
+                if (n < Nn && kk < K && c < C) val = src[(size_t)(head * C + c) * ld + n];
+            }
+            v[u] = val;
+        }
+        const int chunk = k / kCk, kc = k % kCk;
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t pk = cut_pair(v[0], v[1]);
+            *reinterpret_cast<uint32_t *>(img + (((size_t)chunk * 3 + p) * NnP + n) * kCk + kc) = pk;
+        }
+    }
+}
+
+// att_p[Dp]: att_dst in the head-padded layout (zeros in the padding)
+__global__ void split3_pad_att_kernel(const float *att, int H, int C, int Cp, float *att_p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H * Cp) att_p[i] = (i % Cp) < C ? att[(i / Cp) * C + i % Cp] : 0.f;
+}
+
+// C[M, Nn] (f32, row stride ldc, columns < Nn) = (A + fix)[M, K] * W^T from the chunked image.
+// A: f32 row-major (lda), K % 8 == 0; Kp = round_up(K, 32): the image is zero past K, so whatever
+// finite values the A stream picks up there -- the head of the next row -- multiply zeros.
+// FIX: A[m][k] += da_dst[m * H + k / Cp] * att_p[k]  (Cp % 8 == 0; head_magic = 65536 / (Cp / 8) + 1).
+// A block walks one contiguous chunk of `tiles_per_block` 32-row tiles, 8 at a time (wave w: tile
+// w of the group), addressed by 32-bit byte offsets from the chunk's first row and clamped to the
+// end of the matrix (the host keeps a chunk below 2 GiB).
+template <int NTN, bool FIX>
+__global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
+    const float *__restrict__ A, int lda, const uint16_t *__restrict__ img, float *__restrict__ Cout,
+    int ldc, long long M, int Nn, int K, int Kp, const float *__restrict__ da_dst,
+    const float *__restrict__ att_p, int H, unsigned head_magic, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NnP = NTN * 32;
+    constexpr int kBuf = 3 * NnP * kRowB;                   // one chunk in LDS
+    constexpr int kPieces = 3 * NnP * 4;                     // 16-byte pieces of a chunk
+    constexpr int kStage = (kPieces + kGemmThreads - 1) / kGemmThreads;
+    float *attl = reinterpret_cast<float *>(smem + 2 * kBuf);   // [Kp] (FIX)
+    const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // gridDim.x % 8 == 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int NC = Kp / kCk, S = 2 * NC;
+    const long long tiles = (M + 31) / 32;
+    const long long t_begin = (long long)L * tiles_per_block;
+    if (t_begin >= tiles) return;                            // whole block: no barrier is missed
+    const long long t_end = min(tiles, t_begin + tiles_per_block);
+    const int groups = (int)((t_end - t_begin + kGemmWaves - 1) / kGemmWaves);
+    const long long R0 = t_begin * 32;
+    const char *Ab = reinterpret_cast<const char *>(A + R0 * lda);
+    const unsigned max_off = (unsigned)(((M - 1 - R0) * lda + K - 8) * 4);   // the last 32 bytes
+    const unsigned tsb = (unsigned)kGemmWaves * 32u * (unsigned)lda * 4u;    // this wave's tile stride
+    const unsigned adj_a = tsb - (unsigned)S * 64u;
+    unsigned o_tile = (unsigned)((wave * 32 + r) * lda + half * 8) * 4u;
+    const char *Db = reinterpret_cast<const char *>(FIX ? da_dst + R0 * H : nullptr);
+    const unsigned max_d = FIX ? (unsigned)(((M - 1 - R0) * H + H - 1) * 4) : 0u;
+    const unsigned tsd = (unsigned)kGemmWaves * 32u * (unsigned)H * 4u;
+    unsigned d_tile = (unsigned)((wave * 32 + r) * H) * 4u;
+
+    // staging of one chunk: piece i of the chunk (16 bytes; 4 per row) -> LDS row i / 4
+    u32x4 stg[kStage];
+    auto stage_load = [&](int chunk) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(img + (size_t)chunk * 3 * NnP * kCk);
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            const int i = threadIdx.x + j * kGemmThreads;
+            if (kPieces % kGemmThreads == 0 || i < kPieces) stg[j] = src[i];
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            const int i = threadIdx.x + j * kGemmThreads;
+            if (kPieces % kGemmThreads == 0 || i < kPieces)
+                *reinterpret_cast<u32x4 *>(smem + buf * kBuf + (i >> 2) * kRowB + (i & 3) * 16) = stg[j];
+        }
+    };
+
+    f32x4v ra[2][2];
+    float rd[2];
+    // position q of this wave's A stream in steps from step 0 of its current tile (q < 2 S)
+    auto fetch = [&](int u, int q) {
+        const int sq = q >= S ? q - S : q;
+        const unsigned vo = min(o_tile + (unsigned)q * 64u + (q >= S ? adj_a : 0u), max_off);
+        ra[u][0] = *reinterpret_cast<const f32x4v *>(Ab + vo);
+        ra[u][1] = *reinterpret_cast<const f32x4v *>(Ab + vo + 16);
+        if (FIX) {
+            const unsigned head = ((unsigned)(2 * sq + half) * head_magic) >> 16;
+            const unsigned vd = min(d_tile + (q >= S ? tsd : 0u) + head * 4u, max_d);
+            rd[u] = *reinterpret_cast<const float *>(Db + vd);
+        }
+    };
+
+    if (FIX)
+        for (int i = threadIdx.x; i < Kp; i += kGemmThreads) attl[i] = i < K ? att_p[i] : 0.f;
+    stage_load(0);
+    fetch(0, 0);
+    fetch(1, 1);
+    stage_store(0);
+    __syncthreads();
+
+    for (int grp = 0; grp < groups; ++grp) {
+        const long long tile = t_begin + (long long)grp * kGemmWaves + wave;
+        f32x16 acc[NTN];
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+        for (int c = 0; c < NC; ++c) {
+            const int cur = (grp * NC + c) & 1;
+            stage_load(c + 1 == NC ? 0 : c + 1);             // lands in the other buffer below
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int s = 2 * c + t;
+                f32x4v a0 = ra[t][0], a1 = ra[t][1];
+                if (FIX) {
+                    const int k = s * 16 + half * 8;
+                    a0 += rd[t] * *reinterpret_cast<const f32x4v *>(attl + k);
+                    a1 += rd[t] * *reinterpret_cast<const f32x4v *>(attl + k + 4);
+                }
+                fetch(t, s + 2);
+                float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                u32x4 ap[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ap[p][j] = cut_pair(av[2 * j], av[2 * j + 1]);
+                const unsigned char *bl = smem + cur * kBuf + r * kRowB + t * 32 + half * 16;
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    u32x4 bp[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bp[p] = *reinterpret_cast<const u32x4 *>(bl + (p * NnP + nt * 32) * kRowB);
+                    auto mm = [&](int i, int j, f32x16 cc) {
+                        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, ap[i]), __builtin_bit_cast(bf16x8, bp[j]), cc, 0, 0, 0);
+                    };
+                    acc[nt] = mm(2, 0, acc[nt]);              // small products first
+                    acc[nt] = mm(0, 2, acc[nt]);
+                    acc[nt] = mm(1, 1, acc[nt]);
+                    acc[nt] = mm(1, 0, acc[nt]);
+                    acc[nt] = mm(0, 1, acc[nt]);
+                    acc[nt] = mm(0, 0, acc[nt]);
+                }
+            }
+            stage_store(cur ^ 1);
+            __syncthreads();          // everyone is done with `cur`; the other buffer is complete
+        }
+        // C/D layout: column = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 half
+        if (tile < t_end) {
+            const long long m0 = tile * 32;
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int cn = nt * 32 + r;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long long cm = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
+                    if (cm < M && cn < Nn) Cout[(size_t)cm * ldc + cn] = acc[nt][q];
+                }
+            }
+        }
+        o_tile += tsb;
+        d_tile += tsd;
+    }
+}
+
+// ---- d_W ------------------------------------------------------------------------------------
+// part[block][ch][ldp]: the block's rows' share of d_W^T in the head-padded channel layout.
+// A wave covers channels c0 + 4 m + i (tile i, tile row m) and features f0 + 4 n + t (tile t, tile
+// column n): lane r loads, per node, d_h[c0 + 4 r .. + 3] and x[f0 + 4 r .. + 3]; the MFMA k index
+// is the node (8 per half).  FIX: d_h[n][c] += d_a_dst[n][head(c)] att_p[c] (Cp % 4 == 0: the four
+// channels of a lane share a head).
+constexpr int kDwThreads = 256;
+template <bool FIX>
+__global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
+    const float *__restrict__ dh, int Dp, const float *__restrict__ x, int F,
+    const float *__restrict__ da_dst, const float *__restrict__ att_p, int H, int Cp,
+    long long n_rows, long long rows_per_block, int ldp /* round_up(F, 4) */,
+    float *__restrict__ part /* [gridDim.x][Dp][ldp] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const long long n_beg = (long long)blockIdx.x * rows_per_block;
+    const long long n_end = min(n_rows, n_beg + rows_per_block);
+    float *dst = part + (size_t)blockIdx.x * Dp * ldp;
+    for (int cg = wave & 1; cg * 128 < Dp; cg += 2)
+        for (int fg = wave >> 1; fg * 128 < F; fg += 2) {
+            const int c0 = cg * 128, f0 = fg * 128;
+            const bool c_ok = c0 + 4 * r < Dp, f_ok = f0 + 4 * r < F;      // Dp % 4 == F % 4 == 0
+            const int c = c_ok ? c0 + 4 * r : 0, fx = f_ok ? f0 + 4 * r : 0;
+            const f32x4v attc = FIX ? *reinterpret_cast<const f32x4v *>(att_p + c) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            const int head = c / Cp;
+            f32x16 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
+            f32x4v ra[8], rb[8];
+            float rd[8];
+            auto fetch = [&](long long n0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long long nc = min(n0 + 8 * half + j, n_end - 1);
+                    ra[j] = *reinterpret_cast<const f32x4v *>(dh + (size_t)nc * Dp + c);
+                    rb[j] = *reinterpret_cast<const f32x4v *>(x + (size_t)nc * F + fx);
+                    if (FIX) rd[j] = da_dst[(size_t)nc * H + head];
+                }
+            };
+            if (n_beg < n_end) fetch(n_beg);
+            for (long long n0 = n_beg; n0 < n_end; n0 += 16) {
+                u32x4 ap[3][4], bp[3][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float a[2][4], b[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = 2 * jj + u;
+                        const bool live = n0 + 8 * half + j < n_end;
+                        f32x4v v = ra[j];
+                        if (FIX) v += rd[j] * attc;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a[u][i] = (live && c_ok) ? v[i] : 0.f;
+                            b[u][i] = (live && f_ok) ? rb[j][i] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ap[p][i][jj] = cut_pair(a[0][i], a[1][i]);
+                            bp[p][i][jj] = cut_pair(b[0][i], b[1][i]);
+                        }
+                }
+                if (n0 + 16 < n_end) fetch(n0 + 16);           // in flight during the MFMAs
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        auto mm = [&](int pa, int pb, f32x16 cc) {
+                            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, ap[pa][i]), __builtin_bit_cast(bf16x8, bp[pb][t]),
+                                cc, 0, 0, 0);
+                        };
+                        acc[i][t] = mm(2, 0, acc[i][t]);       // small products first
+                        acc[i][t] = mm(0, 2, acc[i][t]);
+                        acc[i][t] = mm(1, 1, acc[i][t]);
+                        acc[i][t] = mm(1, 0, acc[i][t]);
+                        acc[i][t] = mm(0, 1, acc[i][t]);
+                        acc[i][t] = mm(0, 0, acc[i][t]);
+                    }
+            }
+            // tile (i, t), element (row m, column n = r): channel c0 + 4 m + i, feature f0 + 4 r + t
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int ch = c0 + 4 * ((q & 3) + 8 * (q >> 2) + 4 * half) + i;
+                    if (ch < Dp && f_ok) {
+                        f32x4v o = {acc[i][0][q], acc[i][1][q], acc[i][2][q], acc[i][3][q]};
+                        *reinterpret_cast<f32x4v *>(dst + (size_t)ch * ldp + f0 + 4 * r) = o;
+                    }
+                }
+        }
+}
+
+// d_W[h * C + c][f] = sum over blocks of part[b][h * Cp + c][f]   (fixed order)
+__global__ __launch_bounds__(256) void split3_dw_final_kernel(const float *part, int nblocks, int ldp,
+                                                              int H, int C, int Cp, int F, float *dW) {
+    const int f = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int rg = threadIdx.x >> 5;                            // 8 row groups
+    const int Dp = H * Cp;
+    const size_t bstride = (size_t)Dp * ldp;
+    for (int cp = blockIdx.y * 8 + rg; cp < Dp; cp += gridDim.y * 8) {
+        const int head = cp / Cp, c = cp % Cp;
+        if (c >= C || f >= F) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float *p = part + (size_t)cp * ldp + f;
+        int b = 0;
+        for (; b + 3 < nblocks; b += 4) {
+            s0 += p[(size_t)b * bstride];
+            s1 += p[(size_t)(b + 1) * bstride];
+            s2 += p[(size_t)(b + 2) * bstride];
+            s3 += p[(size_t)(b + 3) * bstride];
+        }
+        for (; b < nblocks; ++b) s0 += p[(size_t)b * bstride];
+        dW[(size_t)(head * C + c) * F + f] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------
+struct SplitGeo {
+    int Cp, Dp, DpP, Fp32, Fk, Dk;   // DpP / Fp32: 32-column tiles; Fk / Dk: the K extents (chunks of 32)
+};
+static SplitGeo split_geo(const gatmi_shape &s) {
+    SplitGeo g;
+    g.Cp = round_up4(s.channels);
+    g.Dp = s.heads * g.Cp;
+    g.DpP = (g.Dp + 31) / 32 * 32;
+    g.Fp32 = (s.in_features + 31) / 32 * 32;
+    g.Fk = g.Fp32;
+    g.Dk = g.DpP;
+    return g;
+}
+static int split_dw_blocks(long long n) {
+    long long b = (n + 2047) / 2048;        // at least 2048 rows per block
+    const int cus = device_cus();
+    if (b > cus) b = cus;
+    return (int)(b < 1 ? 1 : b);
+}
+constexpr size_t kSplitImgElems = (size_t)3 * 256 * 256;
+
+// Operand rows 16-byte aligned and whole 8-element fragments (F % 8 == 0), heads that do not
+// straddle a fragment (Cp % 8 == 0), at most 256 columns either way; tall enough for the streaming
+// kernels to pay (below, the tiled f32 kernels of project.hip stay).
+bool split3_covers(const gatmi_shape &s) {
+    if (s.heads < 1 || s.channels < 1 || s.in_features < 1 || s.num_nodes < 4096) return false;
+    const SplitGeo g = split_geo(s);
+    return s.in_features % 8 == 0 && g.Cp % 8 == 0 && g.DpP <= 256 && g.Fp32 <= 256;
+}
+
+size_t split3_workspace_bytes(const gatmi_shape &s) {
+    if (!split3_covers(s)) return 0;
+    const SplitGeo g = split_geo(s);
+    const size_t part = align_up((size_t)split_dw_blocks(s.num_nodes) * g.Dp * s.in_features * 4);
+    return align_up(kSplitImgElems * 2) + align_up((size_t)g.DpP * 4) + part + 256;
+}
+
+template <bool FIX>
+static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16_t *img, float *C, int ldc,
+                              long long M, int Nn, int K, int Kp, const float *da_dst,
+                              const float *att_p, int H, int Cp, hipStream_t st) {
+    GATMI_REQUIRE(Kp % kCk == 0 && K % 8 == 0 && K >= 8 && Cp % 8 == 0 && tiles_n >= 1 && tiles_n <= 8,
+                  "split projection: K = %d, Kp = %d, %d column tiles", K, Kp, tiles_n);
+    const size_t lds = (size_t)2 * 3 * tiles_n * 32 * kRowB + (FIX ? (size_t)Kp * 4 : 0);
+    const long long tiles = (M + 31) / 32;
+    const int cus = device_cus();
+    long long tpb = (tiles + cus - 1) / cus;                   // tiles per block, whole groups of 8
+    tpb = (tpb + kGemmWaves - 1) / kGemmWaves * kGemmWaves;
+    // a block's rows are addressed with 32-bit byte offsets: below 2 GiB, read-ahead included
+    const long long max_tpb = ((1ll << 31) / ((long long)lda * 128) - 4 * kGemmWaves) / kGemmWaves * kGemmWaves;
+    GATMI_REQUIRE(max_tpb >= kGemmWaves, "split projection: rows of %d floats are too long", lda);
+    if (tpb > max_tpb) tpb = max_tpb;
+    long long blocks = (tiles + tpb - 1) / tpb;
+    blocks = (blocks + 7) / 8 * 8;                             // the XCD-contiguous order
+    const int dev = device_index();
+    const unsigned head_magic = 65536u / (unsigned)(Cp / 8) + 1u;
+#define GATMI_SPLIT3_GEMM(NTV)                                                                       \
+    case NTV: {                                                                                      \
+        auto kern = split3_gemm_kernel<NTV, FIX>;                                                    \
+        static size_t granted[kMaxDevices] = {};   /* the attribute is per kernel and per device */  \
+        if (granted[dev] < lds) {                                                                    \
+            GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+            granted[dev] = lds;                                                                      \
+        }                                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGemmThreads), lds, st, A, lda, img, C, \
+                           ldc, M, Nn, K, Kp, da_dst, att_p, H, head_magic, (int)tpb);               \
+        break;                                                                                       \
+    }
+    switch (tiles_n) {
+        GATMI_SPLIT3_GEMM(1)
+        GATMI_SPLIT3_GEMM(2)
+        GATMI_SPLIT3_GEMM(3)
+        GATMI_SPLIT3_GEMM(4)
+        GATMI_SPLIT3_GEMM(5)
+        GATMI_SPLIT3_GEMM(6)
+        GATMI_SPLIT3_GEMM(7)
+        GATMI_SPLIT3_GEMM(8)
+    }
+#undef GATMI_SPLIT3_GEMM
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+// hp [N, Dp] f32 (head-padded) = x W^T
+int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, float *hp, void *ws,
+                       hipStream_t st) {
+    const SplitGeo g = split_geo(*s);
+    Carver cv(ws);
+    uint16_t *img = cv.take<uint16_t>(kSplitImgElems);
+    const int F = s->in_features;
+    hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
+                       g.Fk, 0, s->channels, g.Cp, img);
+    GATMI_HIP(hipGetLastError());
+    return launch_split3_gemm<false>(g.DpP / 32, x, F, img, hp, g.Dp, s->num_nodes, g.Dp, F, g.Fk,
+                                     nullptr, nullptr, s->heads, g.Cp, st);
+}
+
+// d_weight [H*C, F] = (d_hp + d_a_dst att_dst)^T x and d_x [N, F] = (d_hp + d_a_dst att_dst) W; a
+// NULL output is skipped, d_a_dst NULL: no correction.
+int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight, const float *d_hp,
+                       const float *d_a_dst, const float *att_dst, float *d_weight, float *d_x,
+                       void *ws, hipStream_t st) {
+    const SplitGeo g = split_geo(*s);
+    Carver cv(ws);
+    uint16_t *img = cv.take<uint16_t>(kSplitImgElems);
+    float *att_p = cv.take<float>(g.DpP);
+    const long long N = s->num_nodes;
+    const int F = s->in_features, H = s->heads;
+    const int nblocks = split_dw_blocks(N);
+    float *part = cv.take<float>((size_t)nblocks * g.Dp * F);
+    if (d_a_dst) {
+        hipLaunchKernelGGL(split3_pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst,
+                           H, s->channels, g.Cp, att_p);
+        GATMI_HIP(hipGetLastError());
+    }
+    if (d_x) {
+        ProfScope ps("proj_bwd_x_gemm", st);
+        hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, F, g.Dp,
+                           g.Fp32, g.Dk, 1, s->channels, g.Cp, img);
+        GATMI_HIP(hipGetLastError());
+        int e;
+        if (d_a_dst)
+            e = launch_split3_gemm<true>(g.Fp32 / 32, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.Dk, d_a_dst,
+                                         att_p, H, g.Cp, st);
+        else
+            e = launch_split3_gemm<false>(g.Fp32 / 32, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.Dk, nullptr,
+                                          nullptr, H, g.Cp, st);
+        if (e) return e;
+    }
+    if (d_weight) {
+        ProfScope ps("proj_bwd_w_gemm", st);
+        const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
+        if (d_a_dst)
+            hipLaunchKernelGGL(split3_dw_kernel<true>, dim3(nblocks), dim3(kDwThreads), 0, st, d_hp, g.Dp,
+                               x, F, d_a_dst, att_p, H, g.Cp, N, rpb, F, part);
+        else
+            hipLaunchKernelGGL(split3_dw_kernel<false>, dim3(nblocks), dim3(kDwThreads), 0, st, d_hp, g.Dp,
+                               x, F, d_a_dst, att_p, H, g.Cp, N, rpb, F, part);
+        GATMI_HIP(hipGetLastError());
+        hipLaunchKernelGGL(split3_dw_final_kernel, dim3((F + 31) / 32, 16), dim3(256), 0, st, part,
+                           nblocks, F, H, s->channels, g.Cp, F, d_weight);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}
+
+}  // namespace gatmi

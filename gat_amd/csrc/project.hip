@@ -1196,7 +1196,16 @@ extern "C" size_t gatmi_project_workspace_bytes(const gatmi_shape *s) {
     const size_t Cp = round_up4(s->channels), Dp = Cp * s->heads, F = s->in_features;
     const size_t wp = align_up(Dp * F * 4);
     const size_t slab = align_up((size_t)dweight_splits(s->num_nodes, (int)Dp, (int)F) * Dp * F * 4);
-    return wp + slab + align_up(Dp * 4) + 256;
+    return wp + slab + align_up(Dp * 4) + 256 + split3_workspace_bytes(*s);
+}
+
+// where the split-GEMM region of the workspace starts (behind everything the f32 kernels use)
+static void *split3_ws(const gatmi_shape *s, void *ws) {
+    return static_cast<char *>(ws) + (gatmi_project_workspace_bytes(s) - split3_workspace_bytes(*s));
+}
+// GATMI_SPLIT3 bits: 1 forward product, 2 d_x, 4 d_weight (0: all three on the f32 MFMA kernels)
+static int split3_mask(const gatmi_shape *s) {
+    return split3_covers(*s) ? option("GATMI_SPLIT3", 7) & 7 : 0;
 }
 
 static const float *padded_weight(const gatmi_shape *s, const float *weight, float *wp_buf,
@@ -1226,6 +1235,11 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
     const int Cp = round_up4(C), Dp = H * Cp;
     GATMI_REQUIRE(Cp <= 1024, "channels %d too wide", C);
     if (N == 0) return GATMI_OK;
+    if (split3_mask(s) & 1) {
+        // f32-accurate product from three bf16 pieces per operand on the bf16 matrix cores
+        ProfScope ps("proj_fwd_gemm", st);
+        if (int e = split3_project_fwd(s, x, weight, hp, split3_ws(s, ws), st)) return e;
+    } else {
     const float *wp = padded_weight(s, weight, static_cast<float *>(ws), st);
     GATMI_HIP(hipGetLastError());
     {
@@ -1246,6 +1260,7 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
         } else if (int e = launch_gemm(false, false, x, F, wp, F, hp, Dp, N, Dp, F, 1, st)) {
             return e;
         }
+    }
     }
     if (a_dst) {
         ProfScope ps("proj_row_dots", st);
@@ -1285,6 +1300,16 @@ extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int N = s->num_nodes, F = s->in_features, H = s->heads, C = s->channels;
     const int Cp = round_up4(C), Dp = H * Cp;
+    if (const int sp = N > 0 ? split3_mask(s) : 0; sp & 6) {
+        GATMI_REQUIRE(!d_a_dst || att_dst, "d_a_dst given without att_dst");
+        if (int e = split3_project_bwd(s, x, weight, d_hp, d_a_dst, att_dst,
+                                       (sp & 4) ? d_weight : nullptr, (sp & 2) ? d_x : nullptr,
+                                       split3_ws(s, ws), st))
+            return e;
+        if (sp & 4) d_weight = nullptr;
+        if (sp & 2) d_x = nullptr;
+        if (!d_weight && !d_x) return GATMI_OK;
+    }
     float *wp_buf = static_cast<float *>(ws);
     float *slab = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)Dp * F * 4));
     AFix fix{nullptr, nullptr, H, Cp};

@@ -91,11 +91,28 @@ def test_graph_layout_large_random(cuda):
 
 
 # ------------------------------------------------------------------ projection
+# the last five shapes are tall and 8-aligned: the three-way bf16 split GEMMs of gemm_split3.hip run
+# them (ragged K and column tiles, a single 8-wide head, 8 input features, rows % 32 != 0); `split`
+# = 0 sends the same shapes through the f32 MFMA kernels instead
+@pytest.mark.parametrize("split", [-1, 0])
 @pytest.mark.parametrize("n,f,h,c", [(300, 25, 8, 30), (1000, 1433, 8, 8), (257, 240, 1, 2),
-                                     (129, 128, 4, 64), (5, 3, 3, 5), (700, 64, 1, 7)])
-def test_projection_fwd_bwd(cuda, n, f, h, c):
+                                     (129, 128, 4, 64), (5, 3, 3, 5), (700, 64, 1, 7),
+                                     (5003, 256, 8, 32), (4100, 72, 4, 24), (8192, 64, 1, 8),
+                                     (4097, 8, 2, 40), (20000, 256, 4, 64)])
+def test_projection_fwd_bwd(cuda, n, f, h, c, split):
     from gat_amd import _lib
+    if split == 0 and n < 4096:
+        pytest.skip("not a split-GEMM shape")
     lib = _lib.lib()
+    _lib.set_option("GATMI_SPLIT3", split)
+    try:
+        _projection_fwd_bwd(cuda, lib, n, f, h, c)
+    finally:
+        _lib.set_option("GATMI_SPLIT3", -1)
+
+
+def _projection_fwd_bwd(cuda, lib, n, f, h, c):
+    from gat_amd import _lib
     g = torch.Generator().manual_seed(n + f)
     x = torch.randn(n, f, generator=g)
     w = torch.randn(h * c, f, generator=g) / f ** 0.5
