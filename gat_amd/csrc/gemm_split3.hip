@@ -230,26 +230,45 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
 // A wave covers channels c0 + 4 m + i (tile i, tile row m) and features f0 + 4 n + t (tile t, tile
 // column n): lane r loads, per node, d_h[c0 + 4 r .. + 3] and x[f0 + 4 r .. + 3]; the MFMA k index
 // is the node (8 per half).  FIX: d_h[n][c] += d_a_dst[n][head(c)] att_p[c] (Cp % 4 == 0: the four
-// channels of a lane share a head).
+// channels of a lane share a head).  Lanes past Dp / F load column 0 instead: what they contribute
+// lands in accumulator rows / columns that are never stored.
+// A step is 16 nodes: 96 MFMAs on 24 operand registers (3 pieces x 4 tiles x 2 operands).  The ~420
+// vector instructions that cut the NEXT step's 64 raw values per lane are placed between the MFMAs
+// of the step's second part (a lone wave on its SIMD issues in order: vector work ahead of a block
+// of MFMAs simply adds to it) and the pieces are parked in the lane's own 96 dwords of LDS until the
+// next step reads them back -- two sets of pieces plus the raw values do not fit the 256 vector
+// registers beside 256 accumulators.  The raw registers are reloaded for the step after next as
+// soon as they are cut: loads get the first part of a step to land.
 constexpr int kDwThreads = 256;
+constexpr int kDwLds = 4 * 24 * 64 * 16;       // per wave: 24 operand registers of 64 lanes
+// first of the 16 (i, t) MFMA groups that carries cut work (measured at 2.45 M rows: 6: 1.78 ms, 7: 1.86,
+// 8: 1.84, 9: 1.90; with 5 or fewer hipcc gives up unrolling the step and indexes registers in scratch)
+constexpr int kDwCutStart = 6;
 template <bool FIX>
 __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
     const float *__restrict__ dh, int Dp, const float *__restrict__ x, int F,
     const float *__restrict__ da_dst, const float *__restrict__ att_p, int H, int Cp,
-    long long n_rows, long long rows_per_block, int ldp /* round_up(F, 4) */,
+    long long n_rows, long long rows_per_block, int ldp /* row stride of part: F */,
     float *__restrict__ part /* [gridDim.x][Dp][ldp] */) {
+    __shared__ __attribute__((aligned(16))) unsigned char park[kDwLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
-    const long long n_beg = (long long)blockIdx.x * rows_per_block;
+    const long long n_beg = min(n_rows, (long long)blockIdx.x * rows_per_block);
     const long long n_end = min(n_rows, n_beg + rows_per_block);
+    const long long n_full = n_beg + (n_end - n_beg) / 16 * 16;      // whole 16-node steps end here
     float *dst = part + (size_t)blockIdx.x * Dp * ldp;
+    // operand register s (0..11: A piece p tile i = 4 p + i; 12..23: B), element jj of this lane:
+    // dword [s][jj][lane] -- a wave's store of one element is 256 contiguous bytes
+    unsigned *mine = reinterpret_cast<unsigned *>(park) + wave * (24 * 4 * 64) + lane;
     for (int cg = wave & 1; cg * 128 < Dp; cg += 2)
         for (int fg = wave >> 1; fg * 128 < F; fg += 2) {
             const int c0 = cg * 128, f0 = fg * 128;
             const bool c_ok = c0 + 4 * r < Dp, f_ok = f0 + 4 * r < F;      // Dp % 4 == F % 4 == 0
             const int c = c_ok ? c0 + 4 * r : 0, fx = f_ok ? f0 + 4 * r : 0;
             const f32x4v attc = FIX ? *reinterpret_cast<const f32x4v *>(att_p + c) : f32x4v{0.f, 0.f, 0.f, 0.f};
-            const int head = c / Cp;
+            // 32-bit lane offsets from a uniform row pointer
+            const unsigned va = (unsigned)(8 * half * Dp + c) * 4u, vb = (unsigned)(8 * half * F + fx) * 4u;
+            const unsigned vd = (unsigned)(8 * half * H + c / Cp) * 4u;
             f32x16 acc[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -259,58 +278,94 @@ __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
                     for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
             f32x4v ra[8], rb[8];
             float rd[8];
-            auto fetch = [&](long long n0) {
+            // node pair jj of the step at n0: nodes n0 + 8 half + 2 jj, + 1 (all below n_end)
+            auto fetch_pair = [&](long long n0, int jj) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const long long nc = min(n0 + 8 * half + j, n_end - 1);
-                    ra[j] = *reinterpret_cast<const f32x4v *>(dh + (size_t)nc * Dp + c);
-                    rb[j] = *reinterpret_cast<const f32x4v *>(x + (size_t)nc * F + fx);
-                    if (FIX) rd[j] = da_dst[(size_t)nc * H + head];
+                for (int j = 2 * jj; j < 2 * jj + 2; ++j) {
+                    ra[j] = *reinterpret_cast<const f32x4v *>(reinterpret_cast<const char *>(dh + (n0 + j) * Dp) + va);
+                    rb[j] = *reinterpret_cast<const f32x4v *>(reinterpret_cast<const char *>(x + (n0 + j) * F) + vb);
+                    if (FIX) rd[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(da_dst + (n0 + j) * H) + vd);
                 }
             };
-            if (n_beg < n_end) fetch(n_beg);
-            for (long long n0 = n_beg; n0 < n_end; n0 += 16) {
-                u32x4 ap[3][4], bp[3][4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    float a[2][4], b[2][4];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = 2 * jj + u;
-                        const bool live = n0 + 8 * half + j < n_end;
-                        f32x4v v = ra[j];
-                        if (FIX) v += rd[j] * attc;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            a[u][i] = (live && c_ok) ? v[i] : 0.f;
-                            b[u][i] = (live && f_ok) ? rb[j][i] : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            ap[p][i][jj] = cut_pair(a[0][i], a[1][i]);
-                            bp[p][i][jj] = cut_pair(b[0][i], b[1][i]);
-                        }
+            // a quarter of the cut of node pair jj (channel / feature i of the lane's four): element
+            // jj of six operand registers, parked in LDS
+            auto cut_pair_jj = [&](int jj, int part4 /* which quarter of the pair's work: channel/feature */) {
+                const int i = part4;
+                float a0 = ra[2 * jj][i], a1 = ra[2 * jj + 1][i];
+                if (FIX) {
+                    a0 += rd[2 * jj] * attc[i];
+                    a1 += rd[2 * jj + 1] * attc[i];
                 }
-                if (n0 + 16 < n_end) fetch(n0 + 16);           // in flight during the MFMAs
+                float b0 = rb[2 * jj][i], b1 = rb[2 * jj + 1][i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int p = 0; p < 3; ++p) {
+                    mine[((4 * p + i) * 4 + jj) * 64] = cut_pair(a0, a1);
+                    mine[((12 + 4 * p + i) * 4 + jj) * 64] = cut_pair(b0, b1);
+                }
+            };
+            u32x4 op[24];
+            auto park_load = [&]() {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        auto mm = [&](int pa, int pb, f32x16 cc) {
-                            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, ap[pa][i]), __builtin_bit_cast(bf16x8, bp[pb][t]),
-                                cc, 0, 0, 0);
-                        };
-                        acc[i][t] = mm(2, 0, acc[i][t]);       // small products first
-                        acc[i][t] = mm(0, 2, acc[i][t]);
-                        acc[i][t] = mm(1, 1, acc[i][t]);
-                        acc[i][t] = mm(1, 0, acc[i][t]);
-                        acc[i][t] = mm(0, 1, acc[i][t]);
-                        acc[i][t] = mm(0, 0, acc[i][t]);
+                for (int s2 = 0; s2 < 24; ++s2)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) op[s2][jj] = mine[(s2 * 4 + jj) * 64];
+            };
+            auto mma = [&](int g, int k) {
+                // group g = (i, t), product k of the six: small ones first
+                constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+                const int i = g >> 2, t = g & 3;
+                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, op[4 * pa[k] + i]),
+                    __builtin_bit_cast(bf16x8, op[12 + 4 * pb[k] + t]), acc[i][t], 0, 0, 0);
+            };
+            if (n_beg < n_full) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fetch_pair(n_beg + 8 * 0, jj);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) cut_pair_jj(u >> 2, u & 3);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fetch_pair(min(n_beg + 16, n_full - 16), jj);
+                for (long long n0 = n_beg; n0 < n_full; n0 += 16) {
+                    park_load();
+#pragma unroll
+                    for (int g = 0; g < kDwCutStart; ++g)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) mma(g, k);
+                    __builtin_amdgcn_sched_barrier(0);    // cut work (and its wait for the loads) stays below
+                    // the raw registers hold step n0 + 16 (stale on the last step: its pieces are not used);
+                    // the reload is unconditional (the last steps fetch the last step again) so that
+                    // no branch sits between the loads and their counted waits
+                    const long long n2 = min(n0 + 32, n_full - 16);
+                    constexpr int kM = (16 - kDwCutStart) * 6;
+#pragma unroll
+                    for (int m = 0; m < kM; ++m) {
+                        mma(kDwCutStart + m / 6, m % 6);
+#pragma unroll
+                        for (int u = m * 16 / kM; u < (m + 1) * 16 / kM; ++u) {
+                            cut_pair_jj(u >> 2, u & 3);
+                            if ((u & 3) == 3) fetch_pair(n2, u >> 2);         // pair cut: reload it
+                        }
                     }
+                }
+            }
+            if (n_full < n_end) {                          // the block's last, partial step
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long long nn = n_full + 8 * half + j;
+                    const long long nc = min(nn, n_end - 1);
+                    const bool live = nn < n_end;
+                    const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+                    ra[j] = live ? *reinterpret_cast<const f32x4v *>(dh + (size_t)nc * Dp + c) : z;
+                    rb[j] = live ? *reinterpret_cast<const f32x4v *>(x + (size_t)nc * F + fx) : z;
+                    if (FIX) rd[j] = live ? da_dst[(size_t)nc * H + c / Cp] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) cut_pair_jj(u >> 2, u & 3);
+                park_load();
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) mma(g, k);
             }
             // tile (i, t), element (row m, column n = r): channel c0 + 4 m + i, feature f0 + 4 r + t
 #pragma unroll
@@ -365,7 +420,7 @@ static SplitGeo split_geo(const gatmi_shape &s) {
     return g;
 }
 static int split_dw_blocks(long long n) {
-    long long b = (n + 2047) / 2048;        // at least 2048 rows per block
+    long long b = (n + 511) / 512;          // at least 512 rows (32 steps) per block
     const int cus = device_cus();
     if (b > cus) b = cus;
     return (int)(b < 1 ? 1 : b);

@@ -1205,7 +1205,10 @@ static void *split3_ws(const gatmi_shape *s, void *ws) {
 }
 // GATMI_SPLIT3 bits: 1 forward product, 2 d_x, 4 d_weight (0: all three on the f32 MFMA kernels)
 static int split3_mask(const gatmi_shape *s) {
-    return split3_covers(*s) ? option("GATMI_SPLIT3", 7) & 7 : 0;
+    if (!split3_covers(*s)) return 0;
+    // d_W's row-streaming kernel needs rows to fill the chip; below, the split-K tiles are faster
+    const int dflt = s->num_nodes >= 32768 ? 7 : 3;
+    return option("GATMI_SPLIT3", dflt) & 7;
 }
 
 static const float *padded_weight(const gatmi_shape *s, const float *weight, float *wp_buf,
