@@ -49,7 +49,7 @@ int gatmi_version(void);
 /* Kernel-selection switch for A/B runs and for the parity tests of the fallback kernels
  * (no counterpart in the reference).  name = one of GATMI_STREAM, GATMI_FWD3, GATMI_BWD3,
  * GATMI_BWD2, GATMI_EDGE8, GATMI_GROUPROWS, GATMI_GEMM_V2, GATMI_QGROUP, GATMI_OUTGROUP,
- * GATMI_KRES, GATMI_KREG, GATMI_KREG_TAIL, GATMI_KREG_WIDE, GATMI_DW_STREAM, GATMI_DW_TAIL
+ * GATMI_KRES, GATMI_KREG, GATMI_KREG_TAIL, GATMI_KREG_WIDE, GATMI_DW_STREAM, GATMI_DW_TAIL, GATMI_SPLIT3
  * (what each selects: DESIGN.md section 5, "A/B switches"); value >= 0 sets it, value < 0 hands
  * the decision back to the environment variable of the same name. */
 int gatmi_set_option(const char *name, int value);
@@ -131,7 +131,11 @@ typedef struct gatmi_shape {
 } gatmi_shape;
 
 /* Projection h = lin(x) into the head-padded layout, plus the
- * destination logit a_dst[n,h] = <h[n,h,:], att_dst[h,:]> (row a6).  fp32-input MFMA.
+ * destination logit a_dst[n,h] = <h[n,h,:], att_dst[h,:]> (row a6).  fp32 in, fp32 out, at the
+ * fp32 parity bar: fp32 MFMA, or -- tall layers with F % 8 == 0, Cp % 8 == 0 and at most 256 columns
+ * either way -- six bf16 MFMAs per product on operands cut exactly into three bf16 pieces each
+ * (gemm_split3.hip; gatmi_set_option("GATMI_SPLIT3", 0) keeps them on the fp32 MFMA kernels).  The
+ * workspace query covers both.
  *   x [N,F]   weight [H*C,F]   att_dst [H*C]   ->   hp [N,Dp]   a_dst [N,H]           */
 size_t gatmi_project_workspace_bytes(const gatmi_shape *s);
 int gatmi_project_fwd(const gatmi_shape *s, const float *x, const float *weight,
