@@ -121,5 +121,8 @@ int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight
 int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight, const float *d_hp,
                        const float *d_a_dst, const float *att_dst, float *d_weight, float *d_x,
                        void *ws, hipStream_t st);
+// the row-streaming d_W kernel of gemm_split3.hip with 3 (exact split) or 1 (bf16 rounding) pieces
+int rows_dw(const gatmi_shape *s, const float *x, const float *d_hp, const float *d_a_dst,
+            const float *att_p, float *d_weight, float *part, int nblocks, int pieces, hipStream_t st);
 
 }  // namespace gatmi

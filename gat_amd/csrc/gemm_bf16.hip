@@ -507,7 +507,11 @@ extern "C" int gatmi_project_bwd_bf16(const gatmi_shape *s, const float *x, cons
                                                nullptr, H, g.Cp, st);
         if (e) return e;
     }
-    {
+    if (option("GATMI_DW16_ROWS", 1)) {
+        // the row-streaming kernel of gemm_split3.hip with one piece per operand
+        ProfScope ps("proj16_bwd_w_gemm", st);
+        return rows_dw(s, x, d_hp, d_a_dst, att_p, d_weight, part, nblocks, 1, st);
+    } else {
         ProfScope ps("proj16_bwd_w_gemm", st);
         const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
         if (d_a_dst)

@@ -244,7 +244,7 @@ constexpr int kDwLds = 4 * 24 * 64 * 16;       // per wave: 24 operand registers
 // first of the 16 (i, t) MFMA groups that carries cut work (measured at 2.45 M rows: 6: 1.78 ms, 7: 1.86,
 // 8: 1.84, 9: 1.90; with 5 or fewer hipcc gives up unrolling the step and indexes registers in scratch)
 constexpr int kDwCutStart = 6;
-template <bool FIX>
+template <bool FIX, int NP /* pieces per operand: 3 = exact split, 1 = plain bf16 rounding */>
 __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
     const float *__restrict__ dh, int Dp, const float *__restrict__ x, int F,
     const float *__restrict__ da_dst, const float *__restrict__ att_p, int H, int Cp,
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
     const long long n_end = min(n_rows, n_beg + rows_per_block);
     const long long n_full = n_beg + (n_end - n_beg) / 16 * 16;      // whole 16-node steps end here
     float *dst = part + (size_t)blockIdx.x * Dp * ldp;
+    constexpr int NPROD = NP == 3 ? 6 : 1;                            // MFMAs per (i, t) tile pair and step
     // operand register s (0..11: A piece p tile i = 4 p + i; 12..23: B), element jj of this lane:
     // dword [s][jj][lane] -- a wave's store of one element is 256 contiguous bytes
     unsigned *mine = reinterpret_cast<unsigned *>(park) + wave * (24 * 4 * 64) + lane;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
                 }
                 float b0 = rb[2 * jj][i], b1 = rb[2 * jj + 1][i];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     mine[((4 * p + i) * 4 + jj) * 64] = cut_pair(a0, a1);
                     mine[((12 + 4 * p + i) * 4 + jj) * 64] = cut_pair(b0, b1);
                 }
@@ -307,16 +308,19 @@ __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
             auto park_load = [&]() {
 #pragma unroll
                 for (int s2 = 0; s2 < 24; ++s2)
+                    if (s2 % 12 < 4 * NP) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) op[s2][jj] = mine[(s2 * 4 + jj) * 64];
+                        for (int jj = 0; jj < 4; ++jj) op[s2][jj] = mine[(s2 * 4 + jj) * 64];
+                    }
             };
             auto mma = [&](int g, int k) {
                 // group g = (i, t), product k of the six: small ones first
                 constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
                 const int i = g >> 2, t = g & 3;
+                const int qa = NP == 3 ? pa[k] : 0, qb = NP == 3 ? pb[k] : 0;
                 acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8, op[4 * pa[k] + i]),
-                    __builtin_bit_cast(bf16x8, op[12 + 4 * pb[k] + t]), acc[i][t], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, op[4 * qa + i]),
+                    __builtin_bit_cast(bf16x8, op[12 + 4 * qb + t]), acc[i][t], 0, 0, 0);
             };
             if (n_beg < n_full) {
 #pragma unroll
@@ -330,16 +334,16 @@ __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
 #pragma unroll
                     for (int g = 0; g < kDwCutStart; ++g)
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) mma(g, k);
+                        for (int k = 0; k < NPROD; ++k) mma(g, k);
                     __builtin_amdgcn_sched_barrier(0);    // cut work (and its wait for the loads) stays below
                     // the raw registers hold step n0 + 16 (stale on the last step: its pieces are not used);
                     // the reload is unconditional (the last steps fetch the last step again) so that
                     // no branch sits between the loads and their counted waits
                     const long long n2 = min(n0 + 32, n_full - 16);
-                    constexpr int kM = (16 - kDwCutStart) * 6;
+                    constexpr int kM = (16 - kDwCutStart) * NPROD;
 #pragma unroll
                     for (int m = 0; m < kM; ++m) {
-                        mma(kDwCutStart + m / 6, m % 6);
+                        mma(kDwCutStart + m / NPROD, m % NPROD);
 #pragma unroll
                         for (int u = m * 16 / kM; u < (m + 1) * 16 / kM; ++u) {
                             cut_pair_jj(u >> 2, u & 3);
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
 #pragma unroll
                 for (int g = 0; g < 16; ++g)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) mma(g, k);
+                    for (int k = 0; k < NPROD; ++k) mma(g, k);
             }
             // tile (i, t), element (row m, column n = r): channel c0 + 4 m + i, feature f0 + 4 r + t
 #pragma unroll
@@ -538,18 +542,37 @@ int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight
     }
     if (d_weight) {
         ProfScope ps("proj_bwd_w_gemm", st);
-        const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
-        if (d_a_dst)
-            hipLaunchKernelGGL(split3_dw_kernel<true>, dim3(nblocks), dim3(kDwThreads), 0, st, d_hp, g.Dp,
-                               x, F, d_a_dst, att_p, H, g.Cp, N, rpb, F, part);
-        else
-            hipLaunchKernelGGL(split3_dw_kernel<false>, dim3(nblocks), dim3(kDwThreads), 0, st, d_hp, g.Dp,
-                               x, F, d_a_dst, att_p, H, g.Cp, N, rpb, F, part);
-        GATMI_HIP(hipGetLastError());
-        hipLaunchKernelGGL(split3_dw_final_kernel, dim3((F + 31) / 32, 16), dim3(256), 0, st, part,
-                           nblocks, F, H, s->channels, g.Cp, F, d_weight);
-        GATMI_HIP(hipGetLastError());
+        return rows_dw(s, x, d_hp, d_a_dst, att_p, d_weight, part, nblocks, 3, st);
     }
+    return GATMI_OK;
+}
+
+// d_weight [H*C, F] = (d_hp + d_a_dst att_p)^T x with `pieces` bf16 pieces per operand (3: the exact
+// split; 1: operands rounded to bf16 -- the bf16 layers of gemm_bf16.hip).  att_p: head-padded
+// att_dst [Dp] (ignored when d_a_dst is NULL); part: nblocks * Dp * F floats.
+int rows_dw(const gatmi_shape *s, const float *x, const float *d_hp, const float *d_a_dst,
+            const float *att_p, float *d_weight, float *part, int nblocks, int pieces, hipStream_t st) {
+    const SplitGeo g = split_geo(*s);
+    const long long N = s->num_nodes;
+    const int F = s->in_features, H = s->heads;
+    GATMI_REQUIRE(F % 4 == 0 && g.Dp % 4 == 0 && nblocks >= 1 && (pieces == 1 || pieces == 3),
+                  "rows_dw: F = %d, Dp = %d, %d blocks, %d pieces", F, g.Dp, nblocks, pieces);
+    const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
+#define GATMI_ROWS_DW(FIXV, NPV)                                                                      \
+    hipLaunchKernelGGL((split3_dw_kernel<FIXV, NPV>), dim3(nblocks), dim3(kDwThreads), 0, st, d_hp, g.Dp, \
+                       x, F, d_a_dst, att_p, H, g.Cp, N, rpb, F, part)
+    if (pieces == 3) {
+        if (d_a_dst) GATMI_ROWS_DW(true, 3);
+        else GATMI_ROWS_DW(false, 3);
+    } else {
+        if (d_a_dst) GATMI_ROWS_DW(true, 1);
+        else GATMI_ROWS_DW(false, 1);
+    }
+#undef GATMI_ROWS_DW
+    GATMI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(split3_dw_final_kernel, dim3((F + 31) / 32, 16), dim3(256), 0, st, part,
+                       nblocks, F, H, s->channels, g.Cp, F, d_weight);
+    GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
 
