@@ -105,9 +105,20 @@ def test_attention_kernels_on_a_bf16_table(cuda, kind, n, f, h, c, p):
 
 @pytest.mark.parametrize("n,f,h,c", [(4099, 256, 4, 64), (3000, 240, 8, 32), (1000, 64, 8, 8 * 4), (5001, 24, 4, 40),
                                      (33, 8, 8, 32), (2500, 136, 2, 128), (1, 16, 4, 64)])
-def test_bf16_projection_gemms(cuda, n, f, h, c):
+@pytest.mark.parametrize("dw_rows", [-1, 0])
+def test_bf16_projection_gemms(cuda, n, f, h, c, dw_rows):
     """gatmi_project_fwd_bf16 / gatmi_project_bwd_bf16 through the C ABI against f64 products of
-    the bf16-ROUNDED operands (what the MFMA multiplies), and, looser, of the unrounded ones."""
+    the bf16-ROUNDED operands (what the MFMA multiplies), and, looser, of the unrounded ones.
+    dw_rows = 0: d_W on the first bf16 kernel instead of the row-streaming one (GATMI_DW16_ROWS)."""
+    from gat_amd import _lib
+    _lib.set_option("GATMI_DW16_ROWS", dw_rows)
+    try:
+        _bf16_projection_gemms(cuda, n, f, h, c)
+    finally:
+        _lib.set_option("GATMI_DW16_ROWS", -1)
+
+
+def _bf16_projection_gemms(cuda, n, f, h, c):
     from gat_amd import ops
     assert ops.project_bf16_supported(f, h, c)
     g = torch.Generator().manual_seed(n + f)
