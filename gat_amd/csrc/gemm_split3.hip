@@ -108,12 +108,13 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
     const int groups = (int)((t_end - t_begin + kGemmWaves - 1) / kGemmWaves);
     const long long R0 = t_begin * 32;
     const char *Ab = reinterpret_cast<const char *>(A + R0 * lda);
-    const unsigned max_off = (unsigned)(((M - 1 - R0) * lda + K - 8) * 4);   // the last 32 bytes
+    // the matrix's last 32 bytes, or -- more than 4 GiB away -- a bound no offset of this block reaches
+    const unsigned max_off = (unsigned)min(((M - 1 - R0) * lda + K - 8) * 4, 0xffffffe0ll);
     const unsigned tsb = (unsigned)kGemmWaves * 32u * (unsigned)lda * 4u;    // this wave's tile stride
     const unsigned adj_a = tsb - (unsigned)S * 64u;
     unsigned o_tile = (unsigned)((wave * 32 + r) * lda + half * 8) * 4u;
     const char *Db = reinterpret_cast<const char *>(FIX ? da_dst + R0 * H : nullptr);
-    const unsigned max_d = FIX ? (unsigned)(((M - 1 - R0) * H + H - 1) * 4) : 0u;
+    const unsigned max_d = FIX ? (unsigned)min(((M - 1 - R0) * H + H - 1) * 4, 0xfffffff0ll) : 0u;
     const unsigned tsd = (unsigned)kGemmWaves * 32u * (unsigned)H * 4u;
     unsigned d_tile = (unsigned)((wave * 32 + r) * H) * 4u;
 

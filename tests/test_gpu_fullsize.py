@@ -208,3 +208,35 @@ def test_eight_heads_wide_rows_at_scale(cuda):
     assert float((o1 - o2).abs().max()) <= 3e-5 * float(o1.abs().max())
     for name, u, v in zip(("weight", "att_src", "att_dst", "bias"), t, t2):
         assert float((u - v).abs().max()) <= 2e-3 * float(v.abs().max()), name
+
+
+def test_split_projection_beyond_four_gib(cuda):
+    """Tall projection whose operands pass 4 GiB (4.3 M rows x 256 floats): the three-way split GEMMs
+    address a block's rows with 32-bit offsets from the block's first row and clamp them to the end
+    of the matrix -- rows at the start, across the 4-GiB mark and at the end against fp64 products,
+    d_W against the f32 MFMA kernels."""
+    from gat_amd import _lib, ops
+    n, f, h, c = 4300003, 256, 4, 64
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.randn(n, f, device=cuda, generator=g)
+    w = torch.randn(h * c, f, device=cuda, generator=g) / 16
+    att = torch.randn(h * c, device=cuda, generator=g)
+    hp, a_dst = ops.project_fwd(x, w, att, h, c)
+    mark = (1 << 32) // (f * 4)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(mark - 300, mark + 300), torch.arange(n - 300, n),
+                      torch.randint(0, n, (2000,))]).to(cuda)
+    ref = x[rows].double() @ w.double().t()
+    assert float((hp[rows].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    d_hp = torch.randn(n, h * c, device=cuda, generator=g)
+    d_a = torch.randn(n, h, device=cuda, generator=g)
+    d_w, d_x = ops.project_bwd(x, w, d_hp, h, c, True, d_a, att)
+    full = d_hp[rows].double() + d_a[rows].double().repeat_interleave(c, 1) * att.double()
+    ref = full @ w.double()
+    assert float((d_x[rows].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    del hp, d_x
+    _lib.set_option("GATMI_SPLIT3", 0)
+    try:
+        d_w0, _ = ops.project_bwd(x, w, d_hp, h, c, False, d_a, att)
+    finally:
+        _lib.set_option("GATMI_SPLIT3", -1)
+    assert float((d_w - d_w0).abs().max()) <= 2e-5 * float(d_w0.abs().max())
