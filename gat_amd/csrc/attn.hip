@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
     const int slot = threadIdx.x & (nslot - 1);
     const float4 b4 = bias ? ld4(bias + slot * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int UN = 4;
+    constexpr int UN = 8;
     for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 - threadIdx.x % 64 < nq;
          q0 += stride * UN) {
         float4 g4[UN], o4[UN];
@@ -565,8 +565,29 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
         const long long r0 = (long long)blockIdx.x * rows_per_block;
         const long long r1 = min(n_max, r0 + rows_per_block);
         const bool same = dst_off == 0;
+        long long r = r0 + rsub;
+        if (same && n_src == n_dst && !dhp) {
+            // the common case (one shard, the d_a_dst term deferred to the GEMMs): four rows in flight
+            // per thread, every load issued before the first use
+            for (; r + 3 * rows_per_pass < r1; r += 4 * rows_per_pass) {
+                float4 hv[4];
+                float ws[4], wd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long ru = r + u * rows_per_pass;
+                    hv[u] = ld_own<RAW>(hp, (size_t)ru, Dp, slot * 4);
+                    ws[u] = da_src[ru * H + head];
+                    wd[u] = da_dst[ru * H + head];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fma4(a, ws[u], hv[u]);
+                    fma4(b, wd[u], hv[u]);
+                }
+            }
+        }
 #pragma unroll 4
-        for (long long r = r0 + rsub; r < r1; r += rows_per_pass) {
+        for (; r < r1; r += rows_per_pass) {
             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < n_src) {
                 hv = ld_own<RAW>(hp, (size_t)r, Dp, slot * 4);

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void row_dots_flat_kernel(const float *hp, con
                                                             int lph_log, int Cp) {
     const int lph = 1 << lph_log;
     const long long stride = (long long)gridDim.x * 256;
-    constexpr int UN = 4;
+    constexpr int UN = 8;
     for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 - threadIdx.x % 64 < nq;
          q0 += stride * UN) {
         float4 v[UN];
@@ -548,7 +548,9 @@ __global__ __launch_bounds__(256) void row_dots_flat_kernel(const float *hp, con
         for (int u = 0; u < UN; ++u) {
             const long long q = q0 + u * stride;
             const long long grp = q >> lph_log;
-            const int head = (int)(grp % H), sub = (int)(q & (lph - 1));
+            // (a 64-bit remainder is some forty instructions: 32-bit whenever the index allows)
+            const int head = nq < (1ll << 31) ? (int)((unsigned)grp % (unsigned)H) : (int)(grp % H);
+            const int sub = (int)(q & (lph - 1));
             const float4 a4 = *reinterpret_cast<const float4 *>(att_p + head * Cp + sub * 4);
             float p = fmaf(v[u].w, a4.w, fmaf(v[u].z, a4.z, fmaf(v[u].y, a4.y, v[u].x * a4.x)));
             for (int w = 1; w < lph; w <<= 1) p += __shfl_xor(p, w, 64);
@@ -1277,7 +1279,7 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
             hipLaunchKernelGGL(pad_weight_kernel, dim3(1), dim3(256), 0, st, att_dst, att_p, H, C,
                                Cp, 1);
             const long long nq = groups * lph;
-            const long long want = (nq + 256 * 4 - 1) / (256 * 4);
+            const long long want = (nq + 256 * 8 - 1) / (256 * 8);
             hipLaunchKernelGGL(row_dots_flat_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)),
                                dim3(256), 0, st, hp, att_p, a_dst, nq, H, ilog2(lph), Cp);
         } else {
