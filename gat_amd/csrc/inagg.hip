@@ -1720,24 +1720,38 @@ __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const f
                 const int sub = sl + k * gl;
                 if (on && sub < lph) stv4(xs + row * Fs + sub * 4, xv[u][k]);
             }
-            for (int h = 0; h < H; ++h) {
-                f2 ds = {0.f, 0.f}, dd = {0.f, 0.f};
+            // four heads at a time: the row's logits leave as one float4 per table (the pad of
+            // round_up(H, 4) is the zeros of the heads past H)
+            for (int h0 = 0; h0 < H; h0 += 4) {
+                f4 a4 = zero4(), d4 = zero4();
 #pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    const int sub = sl + k * gl;
-                    if (sub < lph) {
-                        pk_dot4(ds, xv[u][k], ldv4(s_wsd + h * Fp + sub * 4));
-                        pk_dot4(dd, xv[u][k], ldv4(s_wsd + HF + h * Fp + sub * 4));
+                for (int i = 0; i < 4; ++i) {
+                    const int h = h0 + i;
+                    if (h < H) {
+                        f2 ds = {0.f, 0.f}, dd = {0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            const int sub = sl + k * gl;
+                            if (sub < lph) {
+                                pk_dot4(ds, xv[u][k], ldv4(s_wsd + h * Fp + sub * 4));
+                                pk_dot4(dd, xv[u][k], ldv4(s_wsd + HF + h * Fp + sub * 4));
+                            }
+                        }
+                        a4[i] = head_sum<GL>(ds.x + ds.y, gl);
+                        d4[i] = head_sum<GL>(dd.x + dd.y, gl);
                     }
                 }
-                const float a = head_sum<GL>(ds.x + ds.y, gl), d = head_sum<GL>(dd.x + dd.y, gl);
                 if (on && sl == 0) {
-                    xs[row * Fs + Fp + h] = a;
-                    a_dst[row * H + h] = d;
+                    stv4(xs + row * Fs + Fp + h0, a4);
+                    if ((H & 3) == 0) {
+                        stv4(a_dst + row * H + h0, d4);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (h0 + i < H) a_dst[row * H + h0 + i] = d4[i];
+                    }
                 }
             }
-            if (on && sl == 0)
-                for (int h = H; h < Fs - Fp; ++h) xs[row * Fs + Fp + h] = 0.f;
         }
     }
 }
