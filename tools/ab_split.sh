@@ -1,4 +1,5 @@
-# usage: tools/_ab.sh lib1 lib2 ...   (names under ab_libs/, "base" = the tree's library)
+# A/B of alternative builds of the library on the split-GEMM probe: tools/ab_split.sh lib1 lib2 ... (names under
+# ab_libs/, loaded through GATMI_LIB; "base" = the tree's library); prints each kernel's rocprofv3 average
 export TMPDIR=/tmp
 for v in "$@"; do
   if [ "$v" = base ]; then unset GATMI_LIB; else export GATMI_LIB=$PWD/ab_libs/$v.so; fi
