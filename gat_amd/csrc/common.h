@@ -116,8 +116,9 @@ int option(const char *name, int dflt);   // gatmi_set_option / environment swit
 // f32-accurate projection GEMMs on the bf16 matrix cores (three-way operand split), gemm_split3.hip
 bool split3_covers(const gatmi_shape &s);
 size_t split3_workspace_bytes(const gatmi_shape &s);
-int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, float *hp, void *ws,
-                       hipStream_t st);
+bool split3_fwd_makes_a_dst(const gatmi_shape &s);   // a_dst comes out of the forward GEMM's epilogue
+int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, const float *att_dst,
+                       float *hp, float *a_dst, void *ws, hipStream_t st);
 int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight, const float *d_hp,
                        const float *d_a_dst, const float *att_dst, float *d_weight, float *d_x,
                        void *ws, hipStream_t st);

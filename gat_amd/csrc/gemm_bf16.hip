@@ -83,10 +83,12 @@ template <int NT, bool OUT_BF16, bool FIX>
 __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
     const float *__restrict__ A, int lda, const uint16_t *__restrict__ img, void *__restrict__ Cout,
     int ldc, long long M, int Nn, int K, int Kp, const float *__restrict__ da_dst,
-    const float *__restrict__ att_p, int H, int Cp) {
+    const float *__restrict__ att_p, int H, int Cp,
+    float *__restrict__ a_dst_out /* OUT_BF16 without FIX: a_dst [M, H] from the ROUNDED rows, or NULL;
+                                     heads are whole column tiles (Cp % 32 == 0) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int SB = (Kp + kKresPad) * 2;                       // image row stride in bytes
-    float *attl = reinterpret_cast<float *>(smem + (size_t)NT * 32 * SB);   // [Kp] (FIX)
+    float *attl = reinterpret_cast<float *>(smem + (size_t)NT * 32 * SB);   // [Kp] (FIX) / [NT * 32] (a_dst)
     {   // fill the image: 16-byte pieces, rows of Kp / 8 pieces
         const int ppr = Kp / 8, total = NT * 32 * ppr;
         for (int i = threadIdx.x; i < total; i += kKresThreads) {
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
         }
         if (FIX)
             for (int i = threadIdx.x; i < Kp; i += kKresThreads) attl[i] = i < K ? att_p[i] : 0.f;
+        if (OUT_BF16 && !FIX && a_dst_out)
+            for (int i = threadIdx.x; i < NT * 32; i += kKresThreads) attl[i] = i < Nn ? att_p[i] : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -173,6 +177,34 @@ __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
                         static_cast<uint16_t *>(Cout)[(size_t)cm * ldc + cn] = (uint16_t)pk;
                     } else if (cn < Nn) {
                         static_cast<float *>(Cout)[(size_t)cm * ldc + cn] = acc[nt][q];
+                    }
+                }
+            }
+        }
+        if constexpr (OUT_BF16 && !FIX) {
+            if (a_dst_out) {          // per head: sum over its tiles, butterfly over the half's 32 lanes
+                const int tph = Cp >> 5;
+                float p[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) p[q] = 0.f;
+                const long long my_row = m0 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;   // lane r < 16: row q = r
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float av = attl[nt * 32 + r];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        p[q] = fmaf(__uint_as_float(pack_bf16(acc[nt][q], 0.f) << 16), av, p[q]);
+                    if ((nt + 1) % tph == 0) {
+                        float keep = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            float v = p[q];
+#pragma unroll
+                            for (int w = 1; w < 32; w <<= 1) v += __shfl_xor(v, w, 64);
+                            keep = r == q ? v : keep;
+                            p[q] = 0.f;
+                        }
+                        if (r < 16 && my_row < M) a_dst_out[my_row * H + nt / tph] = keep;
                     }
                 }
             }
@@ -331,8 +363,10 @@ static int kres_nt(int NnP) { return NnP / 32; }
 template <bool OUT_BF16, bool FIX>
 static int launch_kres_bf16(int NT, const float *A, int lda, const uint16_t *img, void *C, int ldc,
                             long long M, int Nn, int K, int Kp, const float *da_dst,
-                            const float *att_p, int H, int Cp, hipStream_t st) {
-    const size_t lds = (size_t)NT * 32 * (Kp + kKresPad) * 2 + (FIX ? (size_t)Kp * 4 : 0);
+                            const float *att_p, int H, int Cp, hipStream_t st, float *a_dst_out = nullptr) {
+    const size_t lds = (size_t)NT * 32 * (Kp + kKresPad) * 2 + (FIX ? (size_t)Kp * 4 : 0) +
+                       (a_dst_out ? (size_t)NT * 32 * 4 : 0);
+    GATMI_REQUIRE(!a_dst_out || (OUT_BF16 && !FIX && Cp % 32 == 0 && att_p), "bf16 projection: fused a_dst");
     GATMI_REQUIRE(lds <= 160 * 1024, "bf16 projection: %d x %d weights do not fit LDS", NT * 32, Kp);
     const long long tiles = (M + 31) / 32;
     const int per = kKresThreads / 64;
@@ -352,7 +386,7 @@ static int launch_kres_bf16(int NT, const float *A, int lda, const uint16_t *img
             granted[dev] = lds;                                                                      \
         }                                                                                            \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kKresThreads), lds, st, A, lda, img, C, \
-                           ldc, M, Nn, K, Kp, da_dst, att_p, H, Cp);                                 \
+                           ldc, M, Nn, K, Kp, da_dst, att_p, H, Cp, a_dst_out);                      \
         break;                                                                                       \
     }
     switch (NT) {
@@ -439,15 +473,20 @@ extern "C" int gatmi_project_fwd_bf16(const gatmi_shape *s, const float *x, cons
                            s->heads, s->channels, g.Cp, att_p);
         GATMI_HIP(hipGetLastError());
     }
+    bool fused = false;
     {
         ProfScope ps("proj16_fwd_gemm", st);
         // the table's row stride is Dp; the kernel writes DpP >= Dp columns only when DpP == Dp
         GATMI_REQUIRE(g.DpP == g.Dp, "bf16 projection: H * round_up(C, 4) = %d must be a multiple of 32", g.Dp);
+        // heads of whole 32-column tiles: a_dst leaves with the tiles (GATMI_ADST_FUSED=0: own kernel)
+        fused = g.Cp % 32 == 0 && option("GATMI_ADST_FUSED", 1) != 0 &&
+                (size_t)g.DpP * (g.Fp16 + kKresPad) * 2 + (size_t)g.DpP * 4 <= 160 * 1024;
         if (int e = launch_kres_bf16<true, false>(kres_nt(g.DpP), x, F, img, hp16, g.Dp, N, g.Dp, F,
-                                                  g.Fp16, nullptr, nullptr, s->heads, g.Cp, st))
+                                                  g.Fp16, nullptr, fused ? att_p : nullptr, s->heads, g.Cp,
+                                                  st, fused ? a_dst : nullptr))
             return e;
     }
-    {
+    if (!fused) {
         ProfScope ps("proj16_row_dots", st);
         const long long groups = N * s->heads;
         long long blocks = (groups + 255) / 256;

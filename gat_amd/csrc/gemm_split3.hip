@@ -86,11 +86,15 @@ __global__ void split3_pad_att_kernel(const float *att, int H, int C, int Cp, fl
 // A block walks one contiguous chunk of `tiles_per_block` 32-row tiles, 8 at a time (wave w: tile
 // w of the group), addressed by 32-bit byte offsets from the chunk's first row and clamped to the
 // end of the matrix (the host keeps a chunk below 2 GiB).
-template <int NTN, bool FIX>
+// ADST (forward, without FIX): a_dst[m][h] = sum over the head's columns of C[m][.] att_p[.] leaves with
+// the tile -- heads are whole column tiles (tph = Cp / 32 of them); the sums go through a butterfly
+// over the 32 lanes of a half, lane q of the half keeps row q's and stores it.
+template <int NTN, bool FIX, bool ADST>
 __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
     const float *__restrict__ A, int lda, const uint16_t *__restrict__ img, float *__restrict__ Cout,
     int ldc, long long M, int Nn, int K, int Kp, const float *__restrict__ da_dst,
-    const float *__restrict__ att_p, int H, unsigned head_magic, int tiles_per_block) {
+    const float *__restrict__ att_p, int H, unsigned head_magic, int tiles_per_block,
+    float *__restrict__ a_dst_out, int tph) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NnP = NTN * 32;
     constexpr int kBuf = 3 * NnP * kRowB;                   // one chunk in LDS
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
 
     if (FIX)
         for (int i = threadIdx.x; i < Kp; i += kGemmThreads) attl[i] = i < K ? att_p[i] : 0.f;
+    if (ADST)
+        for (int i = threadIdx.x; i < NnP; i += kGemmThreads) attl[i] = i < Nn ? att_p[i] : 0.f;
     stage_load(0);
     fetch(0, 0);
     fetch(1, 1);
@@ -218,6 +224,30 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
                 for (int q = 0; q < 16; ++q) {
                     const long long cm = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
                     if (cm < M && cn < Nn) Cout[(size_t)cm * ldc + cn] = acc[nt][q];
+                }
+            }
+            if (ADST) {
+                float p[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) p[q] = 0.f;
+                const long long my_row = m0 + (r & 3) + 8 * ((r & 15) >> 2) + 4 * half;   // lane r < 16: row q = r
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    const float av = attl[nt * 32 + r];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) p[q] = fmaf(acc[nt][q], av, p[q]);
+                    if ((nt + 1) % tph == 0) {                 // the head's last tile (uniform)
+                        float keep = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            float v = p[q];
+#pragma unroll
+                            for (int w = 1; w < 32; w <<= 1) v += __shfl_xor(v, w, 64);
+                            keep = r == q ? v : keep;
+                            p[q] = 0.f;
+                        }
+                        if (r < 16 && my_row < M) a_dst_out[my_row * H + nt / tph] = keep;
+                    }
                 }
             }
         }
@@ -448,13 +478,15 @@ size_t split3_workspace_bytes(const gatmi_shape &s) {
     return align_up(kSplitImgElems * 2) + align_up((size_t)g.DpP * 4) + part + 256;
 }
 
-template <bool FIX>
+template <bool FIX, bool ADST = false>
 static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16_t *img, float *C, int ldc,
                               long long M, int Nn, int K, int Kp, const float *da_dst,
-                              const float *att_p, int H, int Cp, hipStream_t st) {
+                              const float *att_p, int H, int Cp, hipStream_t st, float *a_dst_out = nullptr) {
     GATMI_REQUIRE(Kp % kCk == 0 && K % 8 == 0 && K >= 8 && Cp % 8 == 0 && tiles_n >= 1 && tiles_n <= 8,
                   "split projection: K = %d, Kp = %d, %d column tiles", K, Kp, tiles_n);
-    const size_t lds = (size_t)2 * 3 * tiles_n * 32 * kRowB + (FIX ? (size_t)Kp * 4 : 0);
+    const size_t lds = (size_t)2 * 3 * tiles_n * 32 * kRowB + (FIX ? (size_t)Kp * 4 : 0) +
+                       (ADST ? (size_t)tiles_n * 32 * 4 : 0);
+    GATMI_REQUIRE(!ADST || (Cp % 32 == 0 && a_dst_out && att_p), "split projection: a_dst needs whole-tile heads");
     const long long tiles = (M + 31) / 32;
     const int cus = device_cus();
     long long tpb = (tiles + cus - 1) / cus;                   // tiles per block, whole groups of 8
@@ -469,7 +501,7 @@ static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16
     const unsigned head_magic = 65536u / (unsigned)(Cp / 8) + 1u;
 #define GATMI_SPLIT3_GEMM(NTV)                                                                       \
     case NTV: {                                                                                      \
-        auto kern = split3_gemm_kernel<NTV, FIX>;                                                    \
+        auto kern = split3_gemm_kernel<NTV, FIX, ADST>;                                              \
         static size_t granted[kMaxDevices] = {};   /* the attribute is per kernel and per device */  \
         if (granted[dev] < lds) {                                                                    \
             GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
@@ -477,7 +509,8 @@ static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16
             granted[dev] = lds;                                                                      \
         }                                                                                            \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGemmThreads), lds, st, A, lda, img, C, \
-                           ldc, M, Nn, K, Kp, da_dst, att_p, H, head_magic, (int)tpb);               \
+                           ldc, M, Nn, K, Kp, da_dst, att_p, H, head_magic, (int)tpb, a_dst_out,     \
+                           Cp / 32);                                                                 \
         break;                                                                                       \
     }
     switch (tiles_n) {
@@ -495,13 +528,25 @@ static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16
     return GATMI_OK;
 }
 
-// hp [N, Dp] f32 (head-padded) = x W^T
-int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, float *hp, void *ws,
-                       hipStream_t st) {
+// hp [N, Dp] f32 (head-padded) = x W^T; with att_dst and a_dst, and heads that are whole 32-column tiles
+// (split3_fwd_makes_a_dst), also a_dst [N, H] = <hp[n, h, :], att_dst[h, :]> from the GEMM's epilogue
+bool split3_fwd_makes_a_dst(const gatmi_shape &s) { return split_geo(s).Cp % 32 == 0; }
+int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, const float *att_dst,
+                       float *hp, float *a_dst, void *ws, hipStream_t st) {
     const SplitGeo g = split_geo(*s);
     Carver cv(ws);
     uint16_t *img = cv.take<uint16_t>(kSplitImgElems);
+    float *att_p = cv.take<float>(g.DpP);
     const int F = s->in_features;
+    if (a_dst && att_dst && g.Cp % 32 == 0) {
+        hipLaunchKernelGGL(split3_pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst,
+                           s->heads, s->channels, g.Cp, att_p);
+        hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
+                           g.Fk, 0, s->channels, g.Cp, img);
+        GATMI_HIP(hipGetLastError());
+        return launch_split3_gemm<false, true>(g.DpP / 32, x, F, img, hp, g.Dp, s->num_nodes, g.Dp, F, g.Fk,
+                                               nullptr, att_p, s->heads, g.Cp, st, a_dst);
+    }
     hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
                        g.Fk, 0, s->channels, g.Cp, img);
     GATMI_HIP(hipGetLastError());

@@ -1243,7 +1243,11 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
     if (split3_mask(s) & 1) {
         // f32-accurate product from three bf16 pieces per operand on the bf16 matrix cores
         ProfScope ps("proj_fwd_gemm", st);
-        if (int e = split3_project_fwd(s, x, weight, hp, split3_ws(s, ws), st)) return e;
+        const bool fused = a_dst && att_dst && split3_fwd_makes_a_dst(*s) && option("GATMI_ADST_FUSED", 1);
+        if (int e = split3_project_fwd(s, x, weight, fused ? att_dst : nullptr, hp, fused ? a_dst : nullptr,
+                                       split3_ws(s, ws), st))
+            return e;
+        if (fused) a_dst = nullptr;         // done in the GEMM's epilogue
     } else {
     const float *wp = padded_weight(s, weight, static_cast<float *>(ws), st);
     GATMI_HIP(hipGetLastError());
