@@ -244,9 +244,12 @@ __global__ __launch_bounds__(256) void glue_reduce_bwd_kernel(const GlueArgs A) 
     }
 }
 
-// dsum[k][c] = sum over blocks of partial[b][k][c], fixed order; 16 row groups per column
+// dsum[k][c] = sum over blocks of partial[b][k][c], fixed order; 16 row groups per column.  The two
+// rows also go to copy0 / copy1 when given (d_beta, d_gamma: stored from this kernel, not copied by
+// hipMemcpyAsync -- copy and memset nodes of a captured HIP graph were seen to run out of order).
 __global__ __launch_bounds__(256) void glue_sum_partials_kernel(const float *partial, int nblocks,
-                                                                int cols, int nslot, float *dsum) {
+                                                                int cols, int nslot, float *dsum,
+                                                                float *copy0, float *copy1) {
     __shared__ float red[256];
     const int k = blockIdx.y;
     constexpr int CG = kFinCols, RG = 256 / CG;
@@ -261,6 +264,8 @@ __global__ __launch_bounds__(256) void glue_sum_partials_kernel(const float *par
         float tot = 0.f;
         for (int q = 0; q < RG; ++q) tot += red[threadIdx.x + q * CG];
         dsum[(size_t)k * cols + c] = tot;
+        float *cp = k == 0 ? copy0 : copy1;
+        if (cp) cp[c] = tot;
     }
 }
 
@@ -411,14 +416,9 @@ extern "C" int gatmi_glue_bwd(const gatmi_glue *g, const float *x, const float *
         ProfScope ps("glue_reduce_bwd", st);
         if (g->rows > 0) hipLaunchKernelGGL(glue_reduce_bwd_kernel, dim3(blocks), dim3(256), 0, st, A);
         hipLaunchKernelGGL(glue_sum_partials_kernel, dim3((g->cols + kFinCols - 1) / kFinCols, 2), dim3(256), 0, st,
-                           A.partial, g->rows > 0 ? blocks : 0, g->cols, A.nslot, dsum);
+                           A.partial, g->rows > 0 ? blocks : 0, g->cols, A.nslot, dsum, grad_beta, grad_gamma);
         GATMI_HIP(hipGetLastError());
     }
-    if (grad_beta)
-        GATMI_HIP(hipMemcpyAsync(grad_beta, dsum, (size_t)g->cols * 4, hipMemcpyDeviceToDevice, st));
-    if (grad_gamma)
-        GATMI_HIP(hipMemcpyAsync(grad_gamma, dsum + g->cols, (size_t)g->cols * 4,
-                                 hipMemcpyDeviceToDevice, st));
     if (g->rows == 0) return GATMI_OK;
     {
         ProfScope ps("glue_apply_bwd", st);

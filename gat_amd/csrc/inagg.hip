@@ -321,8 +321,11 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
 
 // chunk_item[k] = first work item that begins at or after edge k << kChunkEdgesLog
 // (chunk_item[n_chunks] = n_items); items are in CSR order, so a chunk is a contiguous range.
+// Also resets the chunk queue of the kernel that follows (a plain store from a kernel node: a
+// hipMemsetAsync node in front of it was seen NOT to take effect in replays of a captured HIP graph).
 __global__ void inagg_chunk_table_kernel(const int *item_beg, int n_items, int n_chunks,
-                                         int *chunk_item) {
+                                         int *chunk_item, int *queue) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *queue = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n_items; i += gridDim.x * blockDim.x) {
         const int b = i < n_items ? item_beg[i] >> kChunkEdgesLog : n_chunks;
         const int bp = i > 0 ? item_beg[i - 1] >> kChunkEdgesLog : -1;
@@ -2196,11 +2199,10 @@ static int stream_launch_rows(InKind k, const InGeo &g, InArgs &A, int *ws, hipS
     A.queue = ws;
     int *table = ws + 64;
     A.chunk_item = table;
-    GATMI_HIP(hipMemsetAsync(A.queue, 0, sizeof(int), st));
     {
         const int blocks = (A.n_items + 256) / 256;
         hipLaunchKernelGGL(inagg_chunk_table_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256),
-                           0, st, A.item_beg, A.n_items, A.n_chunks, table);
+                           0, st, A.item_beg, A.n_items, A.n_chunks, table, A.queue);
         GATMI_HIP(hipGetLastError());
     }
     if (g.LH == 16 && g.T == 2) stream_launch<16, 2>(k, A, st);

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from gat_amd import _lib
 from gat_amd.data import convert_to_graph, synthetic_traces
 from oracle import gat_oracle as O
 
@@ -90,7 +91,11 @@ def test_device_seed_makes_a_captured_layer_step_draw_new_masks(cuda):
     import cases
     ei, n = cases.knn_graph(n=600, f=6, seed=5)
     eid = ei.to(cuda)
-    for f, h, c, grad_x in ((25, 8, 30, False), (240, 8, 30, True)):      # input-side path / projected rows
+    # input-side path / projected rows / projected rows through the streaming (work-queue) forward,
+    # whose queue counter has to be back at zero at every replay (a memset node did not do that
+    # reliably; the chunk-table kernel stores it now)
+    for f, h, c, grad_x, stream in ((25, 8, 30, False, -1), (240, 8, 30, True, -1), (240, 4, 64, True, 1)):
+        _lib.set_option("GATMI_STREAM", stream)
         torch.manual_seed(3)
         conv = GATConv(f, c, heads=h, dropout=0.4).to(cuda).train()
         x = torch.randn(n, f, device=cuda, requires_grad=grad_x)
@@ -120,6 +125,7 @@ def test_device_seed_makes_a_captured_layer_step_draw_new_masks(cuda):
             torch.cuda.synchronize()
             assert int(conv.device_seed) == 12345 + (k + 1) * SEED_STEP
             assert torch.equal(out, eager[k][0]) and torch.equal(conv.lin.weight.grad, eager[k][1]), (f, k)
+    _lib.set_option("GATMI_STREAM", -1)
 
 
 def test_hipgraph_training_matches_eager_training(cuda, tmp_path, monkeypatch):
