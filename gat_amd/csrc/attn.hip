@@ -1009,11 +1009,14 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
         return GATMI_ERR_WS;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const BwdWs w = carve_bwd(g, &a->shape, geo, ws, bf);
+    BwdWs w = carve_bwd(g, &a->shape, geo, ws, bf);
     const int N = g->num_dst, NS = g->num_src, H = a->shape.heads, C = a->shape.channels;
     GATMI_REQUIRE(d_a_dst_out || N == NS,
                   "a destination partition must take d_a_dst (the d_h fix-up follows its reduce-scatter)");
     if (NS == 0) return GATMI_OK;
+    // the caller's d_a_dst (destination rows owned elsewhere) is written in place: no copy node in
+    // a captured step
+    if (d_a_dst_out) w.da_dst = d_a_dst_out;
     const int prep_blocks = N < kColsumBlocks ? (N > 0 ? N : 1) : kColsumBlocks;
     float *gsum_partial = w.colsum + (size_t)kColsumBlocks * 2 * geo.Dp;
 
@@ -1102,9 +1105,6 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
                                geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
             GATMI_HIP(hipGetLastError());
         }
-        if (d_a_dst_out)
-            GATMI_HIP(hipMemcpyAsync(d_a_dst_out, w.da_dst, (size_t)N * H * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st));
     }
     return GATMI_OK;
 }
