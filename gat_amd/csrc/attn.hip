@@ -466,6 +466,106 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
     GATMI_ITEM_LOOP_END
 }
 
+// The same pass with the softmax chain hoisted out of the row loop (full-wave rows of H = 64 / LPH2
+// heads: 4x64, 8x32).  Above, every edge costs a second 64-lane load instruction (the destination's
+// 16-byte record per head, one address per head group), an exponential and the chain's selects, and
+// one store instruction with H live lanes for d_u.  Here the chain of a 64-edge chunk runs
+// lane-parallel, one (edge, head) pair per lane and pass: the records arrive in H coalesced
+// loads, (a~, a~ slope, -a S slope) go to this wave's LDS table, the row loop reads its head's entry
+// (one ds_read_b128), d_u = d2 * c1 + c0 goes back into the table and leaves in H coalesced stores
+// when the chunk is done.
+template <int LPH2_T, class RAW>
+__global__ __launch_bounds__(256) void attn_bwd_edge2_kernel(const RowArgs A) {
+    constexpr int G = 64, T = 1, H = 64 / LPH2_T, HLOG = (H == 8 ? 3 : (H == 4 ? 2 : (H == 2 ? 1 : 0))),
+                  EPP = 64 / H;
+    static_assert(H * LPH2_T == 64 && (1 << HLOG) == H, "full-wave rows of 1, 2, 4 or 8 heads");
+    constexpr int U = sizeof(RAW) == 8 ? GATMI_U16 : GATMI_U;
+    __shared__ float4 cs_all[4][64 * H];
+    float4 *cs = cs_all[threadIdx.x >> 6];                       // [edge of the chunk][head]
+    GATMI_ITEM_LOOP_BEGIN
+    (void)S.coff; (void)vec_ok; (void)gbase; (void)lig;
+    const int myhead = lane / LPH2_T;                            // the head whose channels this lane holds
+    const int hh = lane & (H - 1);                               // the head of this lane's chain pairs
+    const float4 att = ld4(A.att_src + myhead * A.C + (lane % LPH2_T) * 4);
+    const float4 hj = ld_own<RAW>(A.hself, (size_t)row, A.Dp, lane * 4);
+    const float asj = head_sum<LPH2_T>(dot4(hj, att), lph2);
+    const float as_h = __shfl(asj, hh * LPH2_T, 64);             // head hh's source logit
+    const unsigned offb = (unsigned)lane * 16u;
+    const bool writer = (lane % LPH2_T) == 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float das = 0.f;
+    for (int c = beg; c < end; c += 64) {
+        const int n = min(64, end - c);
+        const int cl = min(lane, n - 1);
+        const int ci = A.col[c + cl];
+        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+                                      (long long)A.aux[c + cl], A.H);
+        auto load = [&](RAW(&v)[U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = __builtin_amdgcn_readlane(ci, min(k0 + u, n - 1));
+                v[u] = ld_slot<G, RAW>(A.hp, i, A.Dp, offb);
+            }
+        };
+        RAW va[U], vb[U];
+        load(va, 0);
+        // the chain: pass ps covers edges EPP * ps .. EPP * ps + EPP - 1, lane -> (edge, head hh)
+#pragma unroll
+        for (int ps = 0; ps < H; ++ps) {
+            if (EPP * ps < n) {                                   // wave-uniform
+                const int e = EPP * ps + (lane >> HLOG);
+                const int ec = min(e, n - 1);
+                const int i = __shfl(ci, ec, 64);
+                const unsigned sb = (unsigned)__shfl(kb, ec, 64);
+                const float4 q = ld4(A.nodeinfo + ((size_t)i * H + hh) * 4);
+                const float uu = as_h + q.x;
+                const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                const float alpha = e < n ? exp_quick(uu * slope - q.y) : 0.f;
+                const float at = ((sb >> hh) & 1u) ? alpha * A.inv_keep : 0.f;
+                cs[64 * ps + lane] = make_float4(at, at * slope, -alpha * q.z * slope, 0.f);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        auto reduce = [&](const RAW(&raw)[U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k0 + u < n;
+                const int kk = min(k0 + u, n - 1);
+                const float4 v = widen(raw[u]);
+                const float d2 = head_sum<LPH2_T>(dot4(v, hj), lph2);
+                const float4 cc = cs[kk * H + myhead];
+                const float du = live ? fmaf(d2, cc.y, cc.z) : 0.f;
+                fma4(acc, live ? cc.x : 0.f, v);
+                das += du;
+                if (live && writer) cs[kk * H + myhead].w = du;
+            }
+        };
+        for (int k0 = 0; k0 < n; k0 += 2 * U) {
+            load(vb, k0 + U);
+            reduce(va, k0);
+            load(va, k0 + 2 * U);
+            reduce(vb, k0 + U);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // d_u of the chunk: [edge][head] is contiguous in du_t
+#pragma unroll
+        for (int ps = 0; ps < H; ++ps)
+            if (EPP * ps + (lane >> HLOG) < n)
+                A.du_t[(size_t)(c + EPP * ps) * H + lane] = cs[64 * ps + lane].w;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (slot < 0) {
+        float4 o = acc;
+        fma4(o, das, att);
+        st4(A.dhp + (size_t)row * A.Dp + lane * 4, o);
+        if (writer) A.da_src[(size_t)row * A.H + myhead] = das;
+    } else {
+        st4(A.part_dh + (size_t)slot * A.Dp + lane * 4, acc);
+        if (writer) A.part_das[(size_t)slot * A.H + myhead] = das;
+    }
+    GATMI_ITEM_LOOP_END
+}
+
 // Merge of the partial (d_h, d_a_src) of source rows cut into segments; segment order fixed.
 __global__ __launch_bounds__(256) void attn_bwd_edge_merge_kernel(
     const int *split_row, const int *split_slot, int n_split, int H, int C, int Cp, int Dp,
@@ -710,6 +810,16 @@ enum Kind { FWD, BWD_EDGE };
 
 template <int LPH2_T, int G, int T>
 static void launch_kind(Kind k, const RowArgs &A, int grid, hipStream_t st) {
+    if constexpr (G == 64 && T == 1 && (LPH2_T == 16 || LPH2_T == 8)) {
+        // full-wave rows without idle lanes (4x64, 8x32): the chain runs per chunk, not per edge
+        if (k == BWD_EDGE && A.H * LPH2_T == 64 && A.C == LPH2_T * 4 && option("GATMI_BWD_HOIST", 1) != 0) {
+            if (A.feat_bf16)
+                hipLaunchKernelGGL((attn_bwd_edge2_kernel<LPH2_T, bf16x4>), dim3(grid), dim3(256), 0, st, A);
+            else
+                hipLaunchKernelGGL((attn_bwd_edge2_kernel<LPH2_T, float4>), dim3(grid), dim3(256), 0, st, A);
+            return;
+        }
+    }
     if constexpr (G == 64) {      // bf16 feature tables: full-wave rows only (make_geometry.G == 64)
         if (A.feat_bf16) {
             if (k == FWD)

@@ -23,6 +23,15 @@
 #ifndef GATMI_INAGG_U2
 #define GATMI_INAGG_U2 2
 #endif
+#ifndef GATMI_E8_UF      // 8 heads, rows of 17..32 float4: instructions (of two edges) per bank, forward / backward
+#define GATMI_E8_UF 2
+#endif
+#ifndef GATMI_E8_UB
+#define GATMI_E8_UB 2
+#endif
+#ifndef GATMI_E8_OCC     // blocks per CU the 8-head backward is compiled for
+#define GATMI_E8_OCC 3
+#endif
 #include "attn_device.h"
 #include "common.h"
 #include <stdlib.h>
@@ -1127,7 +1136,7 @@ template <int OP, int LOW> __device__ __forceinline__ float high_lanes_reduce(fl
 }
 
 template <int LRL, int HPL, int U>
-__global__ __launch_bounds__(256, HPL == 3 ? 3 : 4) void inagg_bwde_kernel(const InArgs A) {
+__global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_kernel(const InArgs A) {
     constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, ROWF = HP * LR * 4, EPP = 64 >> HPL;
     __shared__ f2 cs_all[4][64 * HP];
     __shared__ __attribute__((aligned(16))) float yd_all[4][ROWF];
@@ -2118,7 +2127,7 @@ static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, h
         if (g.H2 == 4) edge8_launch<5, 2, 4, 2>(k, A, grid, st);
         else if (lrl == 3) edge8_launch<3, 3, 1, 1>(k, A, grid, st);
         else if (lrl == 4) edge8_launch<4, 3, 2, 2>(k, A, grid, st);
-        else edge8_launch<5, 3, 2, 2>(k, A, grid, st);
+        else edge8_launch<5, 3, GATMI_E8_UF, GATMI_E8_UB>(k, A, grid, st);
         GATMI_HIP(hipGetLastError());
         return GATMI_OK;
     }
@@ -2161,6 +2170,10 @@ static bool stream_ok(const InGeo &g, int H, long long num_src, int mode) {
     if (!(g.G == 64 && g.Fs / 4 <= 64 && H <= kStreamMaxHeads)) return false;
     if (mode == 2 || (mode == 0 && forced == 0)) return false;
     if (mode == 1 || (mode == 0 && forced == 1)) return true;
+    // 5..8 heads on rows of 9..32 float4: every head group reads the whole row back from the ring
+    // (eight LDS reads of a row per edge); the multi-edge register kernel holds a row once and is
+    // faster there also from HBM (100 -> 8x32 at products size: 8.8 against 10.7 ms)
+    if (edge8_lrl(g, H)) return false;
     return num_src * g.Fs * 4 > (256ll << 20);
 }
 

@@ -71,6 +71,7 @@ SHAPES = {
     "odd_c40": (12, 4, 40),
     "wide_t2": (9, 8, 40),
     "three_heads": (6, 3, 5),
+    "hidden_8x32": (40, 8, 32),   # model.py:28 at hidden_dim 32: full-wave rows of eight heads
     # input layers narrower than their output (the input-side aggregation path)
     "products_l1": (100, 4, 64),  # BASELINE.json config 5
     "arxiv_l1": (128, 4, 64),     # config 3, layer 1

@@ -207,6 +207,33 @@ def test_layer_matches_oracle(cuda, gname, sname, p, seg):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("hoist", [-1, 0], ids=["chunk_chain", "edge_chain"])
+@pytest.mark.parametrize("gname,sname,p,seg", [
+    ("star", "arxiv_h64", 0.4, 64), ("hub_source", "arxiv_h64", 0.0, 64), ("hub_source", "hidden_8x32", 0.425, 64),
+    ("multigraph", "hidden_8x32", 0.0, 512), ("knn", "hidden_8x32", 0.3, 512), ("empty", "hidden_8x32", 0.5, 64)])
+def test_backward_edge_pass_chain_variants(cuda, gname, sname, p, seg, hoist):
+    """Full-wave rows (4x64, 8x32): the transposed-CSR backward with the softmax chain computed per
+    64-edge chunk (default) and per edge in the row loop (GATMI_BWD_HOIST=0), both against the oracle."""
+    from gat_amd import _lib
+    ei, n = cases.GRAPHS[gname]()
+    f, h, c = cases.SHAPES[sname]
+    inputs = cases.layer_inputs(n, f, h, c)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                              mask=mask, training=p > 0)
+    _lib.set_option("GATMI_BWD_HOIST", hoist)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs)
+    finally:
+        _lib.set_option("GATMI_BWD_HOIST", -1)
+    close(out, ref_out, "out")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for k in ref_g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 INAGG_CASES = [
     ("knn", "conv1_h30", 0.425, 512), ("knn", "products_l1", 0.425, 512), ("knn", "arxiv_l1", 0.0, 512),
     ("multigraph", "conv1_h30", 0.0, 64), ("multigraph", "products_l1", 0.3, 64),
