@@ -126,7 +126,8 @@ def main():
 
     from gat_amd import synth
 
-    if world > 1:
+    # GAT_FORCE_PARTITIONED=1: the N>1 path on a one-rank process group (RCCL rehearsal on one GPU)
+    if world > 1 or os.environ.get("GAT_FORCE_PARTITIONED"):
         import torch.distributed as dist
         backend = os.environ.get("GAT_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
