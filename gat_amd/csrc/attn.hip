@@ -83,6 +83,7 @@ struct RowArgs {
 // ---------------------------------------------------------------------------------
 template <int LPH2_T, int G, int T, class RAW>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
 #ifndef GATMI_U16
 #define GATMI_U16 GATMI_U
 #endif
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
         const int n = min(G, end - c);
         const int cl = min(lig, n - 1);
         const int cj = A.col[c + cl];
-        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+        const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
         auto load = [&](RAW(&v)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
 
 template <int LPH2_T, int G, int T, class RAW>
 __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
 #ifndef GATMI_U16
 #define GATMI_U16 GATMI_U
 #endif
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
         const int n = min(G, end - c);
         const int cl = min(lig, n - 1);
         const int ci = A.col[c + cl];
-        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+        const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr,
                                       (long long)A.aux[c + cl], A.H);
         auto load = [&](RAW(&v)[U][T], float4(&q)[U][T], int k0) {
 #pragma unroll
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
 // when the chunk is done.
 template <int LPH2_T, class RAW>
 __global__ __launch_bounds__(256) void attn_bwd_edge2_kernel(const RowArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int G = 64, T = 1, H = 64 / LPH2_T, HLOG = (H == 8 ? 3 : (H == 4 ? 2 : (H == 2 ? 1 : 0))),
                   EPP = 64 / H;
     static_assert(H * LPH2_T == 64 && (1 << HLOG) == H, "full-wave rows of 1, 2, 4 or 8 heads");
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge2_kernel(const RowArgs A) {
         const int n = min(64, end - c);
         const int cl = min(lane, n - 1);
         const int ci = A.col[c + cl];
-        const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+        const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr,
                                       (long long)A.aux[c + cl], A.H);
         auto load = [&](RAW(&v)[U], int k0) {
 #pragma unroll

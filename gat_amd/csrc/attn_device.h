@@ -131,15 +131,21 @@ __device__ __forceinline__ bool keep_hash(uint32_t seed_lo, uint32_t seed_hi, ui
     return (h >> 8) >= thr;   // thr = p * 2^24
 }
 
+// GATMI_MASK_HASH_DEV: the seed lives in device memory (`mask` points at it), so that a captured graph
+// replays with new masks.  Read ONCE at the top of a kernel: inside keep_bits the load sat in the edge
+// loops, and its wait drained the LDS-DMA queue of the streaming forward (6.68 -> 7.31 ms).
+struct KeepSel { int mode; uint64_t seed; };
+__device__ __forceinline__ KeepSel keep_sel(int mode, const uint8_t *mask, uint64_t seed) {
+    if (mode == 3) return KeepSel{2, *reinterpret_cast<const uint64_t *>(mask)};
+    return KeepSel{mode, seed};
+}
+
 // Keep flags of all H (<= 32) heads of one edge, bit h = keep.  Computed lane-parallel
 // (one edge per lane) once per chunk; the per-edge loop then only tests a bit.
+// `mode` and `seed` are what keep_sel returned (GATMI_MASK_HASH_DEV resolved to HASH once per kernel).
 __device__ __forceinline__ uint32_t keep_bits(int mode, const uint8_t *mask, uint64_t seed,
                                               uint32_t thr, long long e, int heads) {
     if (mode == 0) return 0xFFFFFFFFu;
-    if (mode == 3) {    // GATMI_MASK_HASH_DEV: the seed lives in device memory (`mask` points at it),
-        seed = *reinterpret_cast<const uint64_t *>(mask);   // so a captured graph can replay with new masks
-        mode = 2;
-    }
     uint32_t bits = 0;
     if (mode == 1) {
         const uint8_t *m = mask + e * heads;

@@ -150,6 +150,7 @@ struct InArgs {
 // ---------------------------------------------------------------------------------
 template <int LH_T, int G, int T>
 __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 2);
     INAGG_PROLOGUE
     INAGG_ITEM_LOOP
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_kernel(const InArgs A) {
             const int n = min(G, end - c);
             const int cl = min(lig, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U][T], float(&as)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -344,6 +345,7 @@ __global__ void inagg_chunk_table_kernel(const int *item_beg, int n_items, int n
 
 template <int LH_T, int T>
 __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     STREAM_PROLOGUE
     __shared__ float s_adst[4][kChunkItems * kStreamMaxHeads];
     float *adl = s_adst[wv];
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
                     const int e = e0 + r;
                     if (e - kbase >= 64) {
                         kbase = e;
-                        kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+                        kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr,
                                             (long long)min(e + lane, end - 1), A.H);
                     }
                     const bool two = r + 1 < cnt;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_stream_kernel(const InArgs A) {
                     if (two) {
                         if (e + 1 - kbase >= 64) {
                             kbase = e + 1;
-                            kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr,
+                            kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr,
                                                 (long long)min(e + 1 + lane, end - 1), A.H);
                         }
                         sb1 = (unsigned)__builtin_amdgcn_readlane(kb, e + 1 - kbase);
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(256) void inagg_fwd_merge_kernel(
 // ---------------------------------------------------------------------------------
 template <int LH_T, int G, int T>
 __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_INAGG_U2 : 2);
     INAGG_PROLOGUE
     f4 ys[T], yd[T];
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256) void inagg_bwd_kernel(const InArgs A) {
             const int n = min(G, end - c);
             const int cl = min(lig, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U][T], float(&as)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -631,6 +634,7 @@ constexpr int kBwd2MaxH2 = 8;
 
 template <int LH_T, int G, int T>
 __global__ __launch_bounds__(256, GATMI_BWD2_OCC) void inagg_bwd2_kernel(const InArgs A, int H2) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int U = (T == 1) ? 4 : (T == 2 ? GATMI_BWD2_U2 : 2);
     __shared__ f2 cs_all[4][64 * kBwd2MaxH2];
     INAGG_PROLOGUE
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(256, GATMI_BWD2_OCC) void inagg_bwd2_kernel(const I
             const int n = min(G, end - c);
             const int cl = min(lig, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U][T], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -758,6 +762,7 @@ __device__ __forceinline__ float quad_heads_sum(float v0, float v1, float v2, fl
 }
 
 __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int U = kBwd3U;
     __shared__ f2 cs_all[4][64 * 4];
     const int lane = threadIdx.x & 63, half = lane >> 5, p = lane & 31, wv = threadIdx.x >> 6;
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
             const int n = min(64, end - c);
             const int cl = min(lane, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -918,6 +923,7 @@ template <int OP> __device__ __forceinline__ float edge_lanes_reduce(float v) {
 }
 
 __global__ __launch_bounds__(256, 4) void inagg_fwd3_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int U = kFwd3U;
     __shared__ __attribute__((aligned(16))) float ws_all[4][64 * 4];
     const int lane = threadIdx.x & 63, half = lane >> 5, p = lane & 31, wv = threadIdx.x >> 6;
@@ -947,7 +953,7 @@ __global__ __launch_bounds__(256, 4) void inagg_fwd3_kernel(const InArgs A) {
             const int n = min(64, end - c);
             const int cl = min(lane, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1137,6 +1143,7 @@ template <int OP, int LOW> __device__ __forceinline__ float high_lanes_reduce(fl
 
 template <int LRL, int HPL, int U>
 __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, ROWF = HP * LR * 4, EPP = 64 >> HPL;
     __shared__ f2 cs_all[4][64 * HP];
     __shared__ __attribute__((aligned(16))) float yd_all[4][ROWF];
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
             const int n = min(64, end - c);
             const int cl = min(lane, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1271,6 +1278,7 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
 
 template <int LRL, int HPL, int U>
 __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, EPP = 64 >> HPL;
     __shared__ __attribute__((aligned(16))) float ws_all[4][64 * HP];
     const int lane = threadIdx.x & 63, eg = lane >> LRL, p = lane & (LR - 1), wv = threadIdx.x >> 6;
@@ -1300,7 +1308,7 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
             const int n = min(64, end - c);
             const int cl = min(lane, n - 1);
             const int cj = A.col[c + cl];
-            const int kb = (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)c + cl, A.H);
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1420,6 +1428,7 @@ __device__ __forceinline__ int groups_max_i(int v) {
 #define GATMI_BWDG_OCC 3
 #endif
 __global__ __launch_bounds__(256, GATMI_FWDG_OCC) void inagg_fwdg_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     const int lane = threadIdx.x & 63, g = lane >> 3, p = lane & 7, wv = threadIdx.x >> 6;
     const int hl_raw = head_of_lane<3>(lane);
     const bool hlok = hl_raw < A.H;
@@ -1452,7 +1461,7 @@ __global__ __launch_bounds__(256, GATMI_FWDG_OCC) void inagg_fwdg_kernel(const I
             const int nw = min(nmax - c, 8);                      // the wave's longest
             const int el = beg + c + min(p, max(n - 1, 0));
             const int cj = n > 0 ? A.col[el] : 0;
-            const int kb = n > 0 ? (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)el, A.H) : 0;
+            const int kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
             f4 v[8];
             float z[8];
             unsigned sb[8];
@@ -1529,6 +1538,7 @@ __global__ __launch_bounds__(256, GATMI_FWDG_OCC) void inagg_fwdg_kernel(const I
 #endif
 constexpr int kBwdgE = GATMI_BWDG_E;
 __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int ROWF = 8 * 8 * 4;                               // [8 heads][8 lanes x float4]
     __shared__ f4 yd_all[4][8 * 64];                              // [wave][head][lane]
     __shared__ __attribute__((aligned(16))) float red_all[2][4][ROWF];
@@ -1580,7 +1590,7 @@ __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const I
             const int nw = min(nmax - c, 8);
             const int el = beg + c + min(p, max(n - 1, 0));
             const int cj = n > 0 ? A.col[el] : 0;
-            const int kb = n > 0 ? (int)keep_bits(A.mask_mode, A.mask, A.seed, A.keep_thr, (long long)el, A.H) : 0;
+            const int kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
             for (int e0 = 0; e0 < nw; e0 += kBwdgE) {             // kBwdgE rows in flight
                 f4 v[kBwdgE];
                 float as[kBwdgE];
