@@ -840,7 +840,11 @@ static void launch_kind(Kind k, const RowArgs &A, int grid, hipStream_t st) {
 
 static int launch_rows(Kind k, const Geometry &g, const RowArgs &A, hipStream_t st) {
     if (A.n_items == 0) return GATMI_OK;
-    const int grid = item_grid(A.n_items, 256 / g.G);
+    // Large graphs: 16384 blocks instead of 2048.  About 1024 blocks are resident, so 2048 ran as two
+    // rounds whose second one tails off; many short blocks let the dispatcher even out the
+    // power-law rows (products size: forward 13.6 -> 13.0 ms, bf16 rows 7.8 -> 6.9 ms; arxiv
+    // size is 3 % slower that way and keeps the small grid).
+    const int grid = item_grid(A.n_items, 256 / g.G, A.n_items >= (1 << 20) ? 16384 : 2048);
     if (g.G == 64) {
         if (g.T == 1) {
             if (g.lph2 == 16) launch_kind<16, 64, 1>(k, A, grid, st);

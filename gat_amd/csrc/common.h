@@ -67,9 +67,9 @@ inline int ilog2(int v) {
 
 // Grid for the grid-stride work-item kernels: enough 256-thread blocks to fill
 // 256 CUs x 8 blocks, a multiple of 8 so the XCD remap is a bijection.
-inline int item_grid(long long n_groups_needed, int groups_per_block) {
+inline int item_grid(long long n_groups_needed, int groups_per_block, int max_blocks = 2048) {
     long long blocks = (n_groups_needed + groups_per_block - 1) / groups_per_block;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 8) blocks = 8;
     return (int)((blocks + 7) / 8 * 8);
 }
