@@ -36,7 +36,7 @@ def test_partitioned_layer_and_network_over_rccl():
 def test_bench_partitioned_path_over_rccl(exchange):
     """bench.py's N>1 branch (gat_amd.dist.bench_partitioned) on a one-rank RCCL group: the JSON line the
     driver would read at N = 2, 4, 8 comes out, with both exchange modes in it."""
-    env = _env(29678)
+    env = _env(29678 if exchange == "auto" else 29680)      # a port of its own per child: no wait for a closed socket
     env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", GAT_FORCE_PARTITIONED="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "arxiv",
                         "--steps", "2", "--warmup", "1", "--exchange", exchange],
