@@ -53,7 +53,7 @@ class InAgg(C.Structure):
                 ("mask_mode", C.c_int32), ("stream", C.c_int32), ("seed", C.c_uint64),
                 ("mask", C.c_void_p), ("xs", C.c_void_p), ("a_dst", C.c_void_p),
                 ("weight", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p),
-                ("bias", C.c_void_p)]
+                ("bias", C.c_void_p), ("xs16", C.c_void_p)]
 
 
 class Glue(C.Structure):
@@ -123,6 +123,8 @@ SYMBOLS = {
     "gatmi_inagg_supported": (C.c_int, [C.POINTER(Shape)]),
     "gatmi_inagg_z_floats": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_inagg_xs_floats": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_inagg_xs16_bytes": (C.c_size_t, [C.POINTER(Shape)]),
+    "gatmi_inagg_table16": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gatmi_inagg_pack_workspace_bytes": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_inagg_pack": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -98,6 +98,7 @@ struct InArgs {
     const uint8_t *mask;
     uint64_t seed;
     const float *xs;     // [num_src, Fs]: x row (Fp floats, zero padded) | a_src (H floats) | pad
+    const void *xs16;    // bf16 copy of that table in 256-byte rows (inagg_table16_kernel), or null
     const float *a_dst;  // [num_dst, H]
     // forward
     float *z, *lse, *part_m, *part_s, *part_acc;
@@ -1407,6 +1408,359 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
 }
 
 // ---------------------------------------------------------------------------------
+// bf16 source rows (gatmi_inagg.xs16; H <= 4, Fp <= 112).  The packed f32 row of the products-
+// shaped layer is 416 bytes = four 128-byte lines per edge, and lines per edge is what these
+// kernels pay for.  The bf16 table keeps a node in ONE 256-byte row, two lines:
+//   piece p = 0..13 (16 bytes): channels 8p .. 8p+7 of x as bf16 (zero beyond F)
+//   piece 14: a_src[0..3] in f32 (logits are NOT rounded: they come from the f32 x)   piece 15: zero
+// Same layout family as the multi-edge kernels above with LR = 16 lanes per row: one wave
+// instruction covers FOUR consecutive edges, a lane holds 8 channels of its edge's row and all
+// four heads (two float4 accumulators per head).  Arithmetic is f32 on the widened values; Z, q,
+// the logits, the softmax and every output stay f32.
+// ---------------------------------------------------------------------------------
+constexpr int kRow16 = 256;              // bytes per row of the bf16 table
+constexpr int kRow16Logits = 224;        // byte offset of a_src[0] in a row
+
+__device__ __forceinline__ void widen8(const uint4 r, f4 &lo, f4 &hi) {
+    lo = f4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+            __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    hi = f4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u),
+            __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+
+// xs [n, Fs] (f32) -> xs16 [n, 256 bytes]; one thread per 16-byte piece
+__global__ __launch_bounds__(256) void inagg_table16_kernel(const float *xs, long long n, int Fp, int Fs,
+                                                            int H, uint4 *out) {
+    const long long total = n * 16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i >> 4;
+        const int p = (int)(i & 15);
+        const float *r = xs + row * Fs;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (p < 14) {                 // Fp and Fs are multiples of 4: whole float4 are x or are not
+            const f4 lo = 8 * p < Fp ? ldv4(r + 8 * p) : zero4();
+            const f4 hi = 8 * p + 4 < Fp ? ldv4(r + 8 * p + 4) : zero4();
+            o = make_uint4(pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]),
+                           pack_bf16(hi[2], hi[3]));
+        } else if (p == 14) {
+            float a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = k < H ? r[Fp + k] : 0.f;
+            o = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]),
+                           __float_as_uint(a[3]));
+        }
+        out[i] = o;
+    }
+}
+
+template <int U>
+__global__ __launch_bounds__(256, 4) void inagg_fwd16_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
+    constexpr int HPL = 2, LRL = 4, HP = 4, EP = 4, EPP = 16;
+    __shared__ __attribute__((aligned(16))) float ws_all[4][64 * HP];
+    const int lane = threadIdx.x & 63, eg = lane >> LRL, p = lane & 15, wv = threadIdx.x >> 6;
+    const int hl_raw = head_of_lane<HPL>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool ok0 = 8 * p < A.Fp, ok1 = 8 * p + 4 < A.Fp;
+    const unsigned offp = ok0 ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const char *tb = reinterpret_cast<const char *>(A.xs16);
+    float *wt = ws_all[wv];                                      // [edge of the chunk][HP heads]
+    const unsigned hbit = 1u << hl;
+    const int stride = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
+        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
+        const int slot = __builtin_amdgcn_readfirstlane(A.item_slot[it]);
+        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+        end = min(end, beg + A.seg_len);
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float m = -INFINITY, ssum = 0.f;
+        f4 acc[HP][2];
+#pragma unroll
+        for (int h = 0; h < HP; ++h) acc[h][0] = acc[h][1] = zero4();
+        for (int c = beg; c < end; c += 64) {
+            const int n = min(64, end - c);
+            const int cl = min(lane, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](uint4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = __shfl(cj, min(k0 + EP * u + eg, n - 1), 64);
+                    v[u] = *reinterpret_cast<const uint4 *>(tb + (size_t)j * kRow16 + offp);
+                }
+            };
+            uint4 va[U], vb[U];
+            load(va, 0);
+            // logits of the chunk, one (edge, head) pair per lane and pass
+            float zz[HP];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int ps = 0; ps < HP; ++ps) {
+                const int e = EPP * ps + (lane >> HPL);
+                zz[ps] = -INFINITY;
+                if (EPP * ps < n) {                               // wave-uniform
+                    const int js = __shfl(cj, min(e, n - 1), 64);
+                    const float uu = *reinterpret_cast<const float *>(tb + (size_t)js * kRow16 +
+                                                                      kRow16Logits + 4 * hl) + adi;
+                    zz[ps] = e < n ? (uu > 0.f ? uu : A.neg_slope * uu) : -INFINITY;
+                }
+                zmax = fmaxf(zmax, zz[ps]);
+            }
+            const float mn = fmaxf(m, high_lanes_reduce<0, HPL>(zmax));
+            const float sc = exp_quick(m - mn);                   // first chunk: exp(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < HP; ++ps) {
+                if (EPP * ps < n) {
+                    const int e = EPP * ps + (lane >> HPL);
+                    const unsigned sb = (unsigned)__shfl(kb, min(e, n - 1), 64);
+                    const float pe = exp_quick(zz[ps] - mn);      // 0 past the end
+                    psum += pe;
+                    wt[e * HP + hl_raw] = (sb & hbit) ? pe * A.inv_keep : 0.f;
+                }
+            }
+            ssum = fmaf(ssum, sc, high_lanes_reduce<1, HPL>(psum));
+            m = mn;
+#pragma unroll
+            for (int h = 0; h < HP; ++h) {
+                const float sh = bcast_head<HPL>(sc, h);
+                pk_scale4(acc[h][0], sh);
+                pk_scale4(acc[h][1], sh);
+            }
+            auto reduce = [&](const uint4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ke = k0 + EP * u + eg;
+                    f4 w4 = *reinterpret_cast<const f4 *>(wt + min(ke, n - 1) * HP);
+                    if (ke >= n) w4 = zero4();
+                    f4 x0, x1;
+                    widen8(v[u], x0, x1);
+#pragma unroll
+                    for (int h = 0; h < HP; ++h) {
+                        pk_fma4(acc[h][0], w4[h], x0);
+                        pk_fma4(acc[h][1], w4[h], x1);
+                    }
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 2 * U * EP) {
+                load(vb, k0 + U * EP);
+                reduce(va, k0);
+                load(va, k0 + 2 * U * EP);
+                reduce(vb, k0 + U * EP);
+            }
+        }
+        // the four lane groups summed different edges
+#pragma unroll
+        for (int h = 0; h < HP; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[h][q][k] = high_lanes_reduce<1, LRL>(acc[h][q][k]);
+        if (slot < 0) {
+            const float inv = ssum > 0.f ? 1.0f / ssum : 0.f;
+            float iv[HP];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) iv[h] = bcast_head<HPL>(inv, h);
+            if (eg == 0) {
+#pragma unroll
+                for (int h = 0; h < HP; ++h)
+                    if (h < A.H) {
+                        f4 o0 = acc[h][0], o1 = acc[h][1];
+                        pk_scale4(o0, iv[h]);
+                        pk_scale4(o1, iv[h]);
+                        float *zr = A.z + (size_t)row * HF + h * A.Fp + p * 8;
+                        if (ok0) stv4(zr, o0);
+                        if (ok1) stv4(zr + 4, o1);
+                    }
+            }
+            if (A.lse && lane < HP && hlok) A.lse[(size_t)row * A.H + hl] = m + logf(ssum);
+        } else {
+            if (eg == 0) {
+#pragma unroll
+                for (int h = 0; h < HP; ++h)
+                    if (h < A.H) {
+                        float *zr = A.part_acc + (size_t)slot * HF + h * A.Fp + p * 8;
+                        if (ok0) stv4(zr, acc[h][0]);
+                        if (ok1) stv4(zr + 4, acc[h][1]);
+                    }
+            }
+            if (lane < HP && hlok) {
+                A.part_m[(size_t)slot * A.H + hl] = m;
+                A.part_s[(size_t)slot * A.H + hl] = ssum;
+            }
+        }
+    }
+}
+
+// blocks per CU / instructions (of four edges) per bank.  Two accumulators and two q pieces per
+// head take 64 registers: at 4 blocks per CU one instruction per bank fits (6.4 ms at products
+// size); two need 163 registers and 3 blocks per CU (7.2 ms), 2 blocks x 3 instructions 9.0 ms.
+#ifndef GATMI_B16_OCC
+#define GATMI_B16_OCC 4
+#endif
+#ifndef GATMI_B16_U
+#define GATMI_B16_U 1
+#endif
+template <int U>
+__global__ __launch_bounds__(256, GATMI_B16_OCC) void inagg_bwd16_kernel(const InArgs A) {
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
+    constexpr int HPL = 2, LRL = 4, HP = 4, EP = 4, EPP = 16, ROWF = HP * 128;
+    __shared__ f2 cs_all[4][64 * HP];
+    __shared__ __attribute__((aligned(16))) float yd_all[4][ROWF];
+    __shared__ __attribute__((aligned(16))) float ys_all[4][ROWF];
+    const int lane = threadIdx.x & 63, eg = lane >> LRL, p = lane & 15, wv = threadIdx.x >> 6;
+    const int hl_raw = head_of_lane<HPL>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool ok0 = 8 * p < A.Fp, ok1 = 8 * p + 4 < A.Fp;
+    const unsigned offp = ok0 ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const char *tb = reinterpret_cast<const char *>(A.xs16);
+    f2 *cs = cs_all[wv];                                         // [edge of the chunk][HP heads]
+    const unsigned hbit = 1u << hl;
+    float *ydl = yd_all[wv];
+    f4 ys[HP][2];
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+        ys[h][0] = ys[h][1] = zero4();
+        if (eg == 0) {
+            stv4(ydl + h * 128 + p * 8, zero4());
+            stv4(ydl + h * 128 + p * 8 + 4, zero4());
+        }
+    }
+    const int stride = gridDim.x * 4;
+    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
+        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
+        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+        end = min(end, beg + A.seg_len);
+        f4 q8[HP][2];
+        float sv[HP];
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+            const size_t o = (size_t)row * HF + h * A.Fp + p * 8;
+            const bool on0 = ok0 && h < A.H, on1 = ok1 && h < A.H;
+            q8[h][0] = on0 ? ldv4(A.q + o) : zero4();
+            q8[h][1] = on1 ? ldv4(A.q + o + 4) : zero4();
+            const f4 z0 = on0 ? ldv4(A.zin + o) : zero4();
+            const f4 z1 = on1 ? ldv4(A.zin + o + 4) : zero4();
+            f2 d = {0.f, 0.f};
+            pk_dot4(d, q8[h][0], z0);
+            pk_dot4(d, q8[h][1], z1);
+            sv[h] = d.x + d.y;
+        }
+        const float S = heads_sum_e<HPL, LRL>(sv, lane);
+        const float lse_i = A.lsein[(size_t)row * A.H + hl];
+        const float adi = A.a_dst[(size_t)row * A.H + hl];
+        float dad = 0.f;
+        for (int c = beg; c < end; c += 64) {
+            const int n = min(64, end - c);
+            const int cl = min(lane, n - 1);
+            const int cj = A.col[c + cl];
+            const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
+            auto load = [&](uint4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = __shfl(cj, min(k0 + EP * u + eg, n - 1), 64);
+                    v[u] = *reinterpret_cast<const uint4 *>(tb + (size_t)j * kRow16 + offp);
+                }
+            };
+            uint4 va[U], vb[U];
+            load(va, 0);
+            // the chain, one (edge, head) pair per lane: edge = EPP * pass + lane / HP, head = hl
+            for (int e0 = 0; e0 < n; e0 += EPP) {
+                const int e = e0 + (lane >> HPL);
+                const int ec = min(e, n - 1);
+                const int js = __shfl(cj, ec, 64);
+                const unsigned sb = (unsigned)__shfl(kb, ec, 64);
+                const float as = *reinterpret_cast<const float *>(tb + (size_t)js * kRow16 +
+                                                                  kRow16Logits + 4 * hl);
+                const float uu = as + adi;
+                const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                const float alpha = (e < n && hlok) ? exp_fast(uu * slope - lse_i) : 0.f;
+                const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
+                cs[e * HP + hl_raw] = f2{at * slope, -alpha * S * slope};
+            }
+            auto reduce = [&](const uint4(&v)[U], int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ke = k0 + EP * u + eg;              // this lane group's edge
+                    f4 x0, x1;
+                    widen8(v[u], x0, x1);
+                    float dv[HP];
+#pragma unroll
+                    for (int h = 0; h < HP; ++h) {
+                        f2 d = {0.f, 0.f};
+                        pk_dot4(d, x0, q8[h][0]);
+                        pk_dot4(d, x1, q8[h][1]);
+                        dv[h] = d.x + d.y;
+                    }
+                    const float d2 = heads_sum_e<HPL, LRL>(dv, lane);
+                    const f2 cc = cs[min(ke, n - 1) * HP + hl_raw];
+                    const float du = ke < n ? fmaf(d2, cc.x, cc.y) : 0.f;
+                    dad += du;
+#pragma unroll
+                    for (int h = 0; h < HP; ++h) {
+                        const float dh = bcast_head<HPL>(du, h);
+                        pk_fma4(ys[h][0], dh, x0);
+                        pk_fma4(ys[h][1], dh, x1);
+                    }
+                }
+            };
+            for (int k0 = 0; k0 < n; k0 += 2 * U * EP) {
+                load(vb, k0 + U * EP);
+                reduce(va, k0);
+                load(va, k0 + 2 * U * EP);
+                reduce(vb, k0 + U * EP);
+            }
+        }
+        // d_wd += (sum of the row's d_u) * x_i (the f32 row: this term is not gathered)
+        {
+            const float dt = high_lanes_reduce<1, LRL>(dad);
+            const float *xr = A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 8;
+            const f4 xi0 = ok0 ? ldv4(xr) : zero4();
+            const f4 xi1 = ok1 ? ldv4(xr + 4) : zero4();
+            float dh[HP];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) dh[h] = bcast_head<HPL>(dt, h);
+            if (eg == 0) {                                        // count the row once
+#pragma unroll
+                for (int h = 0; h < HP; ++h) {
+                    f4 a0 = ldv4(ydl + h * 128 + p * 8), a1 = ldv4(ydl + h * 128 + p * 8 + 4);
+                    pk_fma4(a0, dh[h], xi0);
+                    pk_fma4(a1, dh[h], xi1);
+                    stv4(ydl + h * 128 + p * 8, a0);
+                    stv4(ydl + h * 128 + p * 8 + 4, a1);
+                }
+            }
+        }
+    }
+    // the lane groups accumulated different edges: add them; then the block's four waves are
+    // added in LDS and ONE partial row per block goes out (part_y [blocks][2][H*Fp])
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ys[h][q][k] = high_lanes_reduce<1, LRL>(ys[h][q][k]);
+            if (eg == 0) stv4(ys_all[wv] + h * 128 + p * 8 + 4 * q, ys[h][q]);
+        }
+    }
+    __syncthreads();
+    float *dst = A.part_y + (size_t)blockIdx.x * 2 * HF;
+    for (int idx = threadIdx.x; idx < 2 * ROWF; idx += 256) {
+        const int which = idx / ROWF, r = idx % ROWF, hh = r >> 7, ff = r & 127;
+        if (hh < A.H && ff < A.Fp) {
+            const float(*src)[ROWF] = which ? yd_all : ys_all;
+            dst[which * HF + hh * A.Fp + ff] = (src[0][r] + src[1][r]) + (src[2][r] + src[3][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // A destination row per 8-lane group (5..8 heads, rows of at most 8 float4, LOW degree: run.py's
 // 25 -> 8x30 layer on a 5-nearest-neighbour graph).  With one row per wave an item there is a
 // handful of edges under a whole wave's prologue.  Here a wave takes 8 items at once: the 8
@@ -2187,6 +2541,9 @@ static bool stream_ok(const InGeo &g, int H, long long num_src, int mode) {
     return num_src * g.Fs * 4 > (256ll << 20);
 }
 
+// bf16 source rows (gatmi_inagg.xs16): up to four heads, rows of at most 14 pieces of 8 channels
+static bool rows16_cover(const InGeo &g, int H) { return g.G == 64 && H <= 4 && g.Fp <= 112; }
+
 // Persistent grid: as many blocks as fit on the device at once; chunks come from the queue.
 template <class K> static int resident_blocks(K kernel) {
     int dev = 0, cus = 0, per = 0;
@@ -2258,6 +2615,9 @@ static int check_inagg(const gatmi_graph *g, const gatmi_inagg *a, InGeo *geo) {
     GATMI_REQUIRE(a->stream >= 0 && a->stream <= 2, "bad stream mode %d", a->stream);
     GATMI_REQUIRE(a->xs && a->a_dst && a->weight && a->att_src && a->att_dst,
                   "null xs/a_dst/weight/att_src/att_dst");
+    GATMI_REQUIRE(!a->xs16 || rows16_cover(*geo, a->shape.heads),
+                  "bf16 source rows cover H <= 4 and F <= 112 (got F=%d H=%d)", a->shape.in_features,
+                  a->shape.heads);
     return GATMI_OK;
 }
 
@@ -2284,6 +2644,7 @@ static void fill_in_args(InArgs &A, const gatmi_graph *g, const gatmi_inagg *a, 
     A.mask = a->mask;
     A.seed = a->seed;
     A.xs = a->xs;
+    A.xs16 = a->xs16;
     A.a_dst = a->a_dst;
     A.E = g->num_edges;
 }
@@ -2419,6 +2780,28 @@ extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const floa
     return GATMI_OK;
 }
 
+extern "C" size_t gatmi_inagg_xs16_bytes(const gatmi_shape *s) {
+    InGeo g;
+    if (!s || !make_in_geo(*s, &g) || !rows16_cover(g, s->heads)) return 0;
+    return kRow16;
+}
+
+extern "C" int gatmi_inagg_table16(const gatmi_shape *s, const float *xs, void *xs16, void *stream) {
+    GATMI_REQUIRE(s && xs && xs16, "null shape/xs/xs16");
+    InGeo g;
+    GATMI_REQUIRE(make_in_geo(*s, &g) && rows16_cover(g, s->heads),
+                  "bf16 source rows cover H <= 4 and F <= 112 (got F=%d H=%d)", s->in_features, s->heads);
+    if (s->num_nodes == 0) return GATMI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps("inagg_table16", st);
+    const long long pieces = (long long)s->num_nodes * 16;
+    const int blocks = (int)((pieces + 255) / 256 > 16384 ? 16384 : (pieces + 255) / 256);
+    hipLaunchKernelGGL(inagg_table16_kernel, dim3(blocks), dim3(256), 0, st, xs, (long long)s->num_nodes,
+                       g.Fp, g.Fs, s->heads, static_cast<uint4 *>(xs16));
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
 extern "C" size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s) {
     InGeo geo;
     if (!g || !s || !make_in_geo(*s, &geo)) return 0;
@@ -2461,7 +2844,13 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
         // table beyond the Infinity Cache: the LDS-DMA streaming kernel (6.67 ms against 6.93 ms
         // for the two-edge register layout on the products-shaped layer); else in_launch_rows
         // picks the two-edge layout when it covers the shape (H <= 4), the head-group kernel if not
-        if (stream_ok(geo, H, g->num_src, a->stream)) {
+        if (a->xs16) {
+            if (A.n_items > 0) {
+                                // two instructions of four edges per bank (one: 5.3 ms, three: 5.9 ms at products size)
+                hipLaunchKernelGGL(inagg_fwd16_kernel<2>, dim3(in_grid(geo, A.n_items)), dim3(256), 0, st, A);
+                GATMI_HIP(hipGetLastError());
+            }
+        } else if (stream_ok(geo, H, g->num_src, a->stream)) {
             if (int e = stream_launch_rows(IN_FWD, geo, A, stream_ws, st)) return e;
         } else if (int e = in_launch_rows(IN_FWD, geo, A, in_grid(geo, A.n_items), st)) {
             return e;
@@ -2601,6 +2990,9 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         const int grid = w.waves / 4;
         if (A.n_items == 0) {
             GATMI_HIP(hipMemsetAsync(w.part_y, 0, (size_t)w.waves * 2 * geo.HF * 4, st));
+        } else if (a->xs16) {
+            hipLaunchKernelGGL(inagg_bwd16_kernel<GATMI_B16_U>, dim3(grid), dim3(256), 0, st, A);
+            GATMI_HIP(hipGetLastError());
         } else if (int e = in_launch_rows(IN_BWD, geo, A, grid, st)) {
             return e;
         }
@@ -2608,7 +3000,8 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     {
         ProfScope ps("inagg_colsums", st);
         int prow = w.waves;                                       // partial rows written
-        if (A.n_items > 0 && group_rows(geo, A)) prow = group_rows_grid(A, w.waves / 4);
+        if (A.n_items > 0 && a->xs16) prow = w.waves / 4;           // one partial row per block
+        else if (A.n_items > 0 && group_rows(geo, A)) prow = group_rows_grid(A, w.waves / 4);
         else if (A.n_items > 0 && bwd3_covers(geo, H)) prow = w.waves / 4;
         SumJob j0{w.part_y, w.dwsd, prow, 2 * geo.HF, geo.HF};
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, prow, 2 * geo.HF, geo.HF};

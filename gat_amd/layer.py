@@ -67,17 +67,19 @@ class _GATConvInAggFn(torch.autograd.Function):
         bias_c = None if bias is None else bias.contiguous()
         need_grad = any(ctx.needs_input_grad[1:5])
         xs, a_dst = ops.inagg_pack(x, weight, att_s, att_d, cfg.heads, cfg.channels)
-        out, z, lse = ops.inagg_fwd(layout, cfg, xs, a_dst, weight, att_s, att_d, bias_c, need_grad)
+        # bf16 source rows for the gathers (cfg.rows16): the f32 table stays for the row-local terms
+        xs16 = ops.inagg_table16(xs, x.size(1), cfg.heads, cfg.channels) if getattr(cfg, "rows16", False) else None
+        out, z, lse = ops.inagg_fwd(layout, cfg, xs, a_dst, weight, att_s, att_d, bias_c, need_grad, xs16)
         if need_grad:
-            ctx.save_for_backward(xs, a_dst, weight, att_s, att_d, bias_c, z, lse)
+            ctx.save_for_backward(xs, a_dst, weight, att_s, att_d, bias_c, z, lse, xs16)
             ctx.layout, ctx.cfg, ctx.att_shape = layout, cfg, att_src.shape
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        xs, a_dst, weight, att_s, att_d, bias_c, z, lse = ctx.saved_tensors
+        xs, a_dst, weight, att_s, att_d, bias_c, z, lse, xs16 = ctx.saved_tensors
         d_w, d_as, d_ad, d_b = ops.inagg_bwd(ctx.layout, ctx.cfg, xs, a_dst, weight, att_s, att_d,
-                                             bias_c, z, lse, grad_out.contiguous())
+                                             bias_c, z, lse, grad_out.contiguous(), xs16)
         return None, d_w, d_as.view(ctx.att_shape), d_ad.view(ctx.att_shape), d_b, None, None
 
 
@@ -173,6 +175,9 @@ class GATConv(nn.Module):
             raise RuntimeError("input_aggregation=True cannot produce a gradient for x")
         cfg.feat_bf16 = (not use_inagg and self.feature_dtype == torch.bfloat16 and
                          ops.project_bf16_supported(self.in_channels, self.heads, self.out_channels))
+        # the same switch on the input-side path: the edge kernels gather bf16 copies of the x rows
+        cfg.rows16 = bool(use_inagg and self.feature_dtype == torch.bfloat16 and
+                          ops.inagg_rows16_supported(self.in_channels, self.heads, self.out_channels))
         fn = _GATConvInAggFn if use_inagg else _GATConvFn
         out = fn.apply(x, self.lin.weight, self.att_src, self.att_dst, fused_bias, layout, cfg)
         if not self.concat:

@@ -235,7 +235,31 @@ def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, head
     return xs, a_dst
 
 
-def _inagg_args(cfg: AttnConfig, num_dst, in_features, xs, a_dst, weight, att_src, att_dst, bias):
+def inagg_rows16_supported(in_features: int, heads: int, channels: int) -> bool:
+    """bf16 source rows for the input-side gathers: H <= 4, F <= 112 (inagg.hip rows16_cover)."""
+    shape = _lib.Shape(0, in_features, heads, channels)
+    return int(_lib.lib().gatmi_inagg_xs16_bytes(C.byref(shape))) > 0
+
+
+def inagg_table16(xs: Tensor, in_features: int, heads: int, channels: int) -> Tensor:
+    """packed f32 source rows xs [n, Fs] -> their bf16 copy in 256-byte rows ([n, 128] bfloat16: 14
+    pieces of 8 channels, then the four f32 logits, which are not rounded)."""
+    lib, dev = _lib.lib(), xs.device
+    shape = _lib.Shape(xs.size(0), in_features, heads, channels)
+    row = int(lib.gatmi_inagg_xs16_bytes(C.byref(shape)))
+    if row == 0:
+        raise RuntimeError(f"bf16 source rows do not cover F={in_features} H={heads}")
+    if int(lib.gatmi_inagg_xs_floats(C.byref(shape))) != xs.size(1):
+        raise ValueError("xs row width does not match this layer")
+    with torch.cuda.device(dev):
+        xs16 = torch.empty(xs.size(0), row // 2, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.gatmi_inagg_table16(C.byref(shape), xs.data_ptr(), xs16.data_ptr(), _stream(dev)),
+                   "gatmi_inagg_table16")
+    return xs16
+
+
+def _inagg_args(cfg: AttnConfig, num_dst, in_features, xs, a_dst, weight, att_src, att_dst, bias,
+                xs16=None):
     a = _lib.InAgg()
     a.shape = _lib.Shape(num_dst, in_features, cfg.heads, cfg.channels)
     a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
@@ -243,12 +267,15 @@ def _inagg_args(cfg: AttnConfig, num_dst, in_features, xs, a_dst, weight, att_sr
     a.stream = int(getattr(cfg, "stream", 0))
     a.xs, a.a_dst, a.weight = xs.data_ptr(), a_dst.data_ptr(), weight.data_ptr()
     a.att_src, a.att_dst, a.bias = _ptr(att_src), _ptr(att_dst), _ptr(bias)
+    if xs16 is not None and (xs16.dtype != torch.bfloat16 or xs16.size(0) != xs.size(0) or not xs16.is_contiguous()):
+        raise ValueError("xs16 must be the contiguous bfloat16 table gatmi_inagg_table16 made of xs")
+    a.xs16 = _ptr(xs16)
     return a
 
 
 def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, weight: Tensor,
-              att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], need_lse: bool
-              ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+              att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], need_lse: bool,
+              xs16: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
     """xs [num_src, Fs] (all nodes), a_dst [num_dst, H] -> out [num_dst, H*C], z [num_dst, H*Fp],
     lse [num_dst, H]."""
     lib, dev = _lib.lib(), xs.device
@@ -257,7 +284,7 @@ def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, w
         raise ValueError(f"xs has {xs.size(0)} rows / a_dst {a_dst.size(0)}, the graph "
                          f"{layout.num_nodes} sources / {n} destinations")
     with torch.cuda.device(dev):
-        a = _inagg_args(cfg, n, weight.size(1), xs, a_dst, weight, att_src, att_dst, bias)
+        a = _inagg_args(cfg, n, weight.size(1), xs, a_dst, weight, att_src, att_dst, bias, xs16)
         if int(lib.gatmi_inagg_xs_floats(C.byref(a.shape))) != xs.size(1):
             raise ValueError("xs row width does not match this layer")
         zf = int(lib.gatmi_inagg_z_floats(C.byref(a.shape)))
@@ -273,12 +300,12 @@ def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, w
 
 def inagg_bwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, weight: Tensor,
               att_src: Tensor, att_dst: Tensor, bias: Optional[Tensor], z: Tensor, lse: Tensor,
-              grad_out: Tensor):
+              grad_out: Tensor, xs16: Optional[Tensor] = None):
     """-> d_weight, d_att_src, d_att_dst, d_bias (partial sums on a destination partition)."""
     lib, dev = _lib.lib(), xs.device
     with torch.cuda.device(dev):
         a = _inagg_args(cfg, layout.num_dst, weight.size(1), xs, a_dst, weight, att_src, att_dst,
-                        bias)
+                        bias, xs16)
         d_w = torch.empty_like(weight)
         d_as = torch.empty_like(att_src)
         d_ad = torch.empty_like(att_dst)

@@ -268,6 +268,14 @@ int gatmi_inagg_pack(const gatmi_shape *s /* num_nodes = rows to pack */, const 
                      float *xs /* [rows, Fs] */, float *a_dst /* [rows, H] */,
                      void *ws, size_t ws_bytes, void *stream);
 
+/* bf16 source rows for the gathers of this path (no counterpart in the reference; the "bf16"
+ * of BASELINE.json's north_star applied to the gathered table of model.py:40's layer; tolerance
+ * stated in tests/test_gpu_bf16.py).  gatmi_inagg_xs16_bytes: bytes per row (256), 0 when the
+ * shape is not covered (H <= 4, F <= 112).  gatmi_inagg_table16: xs [num_nodes, Fs] -> xs16. */
+size_t gatmi_inagg_xs16_bytes(const gatmi_shape *s);
+int gatmi_inagg_table16(const gatmi_shape *s /* num_nodes = rows */, const float *xs, void *xs16,
+                        void *stream);
+
 typedef struct gatmi_inagg {
     gatmi_shape shape;     /* num_nodes = destination rows                              */
     float negative_slope;
@@ -284,6 +292,9 @@ typedef struct gatmi_inagg {
     const float *att_src;  /* [H*C]                                                     */
     const float *att_dst;  /* [H*C]                                                     */
     const float *bias;     /* [H*C] or NULL                                             */
+    const void *xs16;      /* NULL, or the bf16 copy of xs made by gatmi_inagg_table16: the edge
+                              kernels then gather its 256-byte rows (two lines instead of four
+                              for F = 100) and keep all arithmetic and every output in f32     */
 } gatmi_inagg;
 
 /*   -> out [num_dst, H*C],  z [num_dst, H*Fp] (the per-head aggregated inputs, kept for the

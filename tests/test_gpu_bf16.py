@@ -257,3 +257,55 @@ def test_bf16_tables_are_refused_for_narrow_rows(cuda):
     v = torch.zeros(64, device=cuda)
     with pytest.raises(RuntimeError, match="bf16 feature tables need"):
         ops.attn_fwd(layout, cfg, 4, z, torch.zeros(n, 8, device=cuda), v, v, v, False)
+
+
+@pytest.mark.parametrize("kind", ["powerlaw", "knn5", "star"])
+@pytest.mark.parametrize("n,f,h,c,p", [(3001, 100, 4, 64, 0.0), (3001, 100, 4, 64, 0.4), (2049, 112, 2, 128, 0.3),
+                                       (1500, 40, 3, 24, 0.0), (900, 108, 4, 40, 0.25)])
+def test_input_side_path_on_bf16_source_rows(cuda, kind, n, f, h, c, p):
+    """GATConv(feature_dtype=torch.bfloat16) on the input-side aggregation path (x is data: no d_x):
+    the edge kernels gather a bf16 copy of the packed x rows (gatmi_inagg_table16, 256-byte rows); the
+    logits, the softmax, Z, q and every output stay f32.  Bar (1): fed an x that bf16 holds exactly,
+    the table is exact and the layer meets the f32 bar against the oracle.  Bar (2): on any x, the
+    stated bf16 tolerance against the f32 oracle."""
+    from gat_amd import GATConv, _lib, ops
+    assert ops.inagg_rows16_supported(f, h, c)
+    ei = graph(kind, n, seed=n + h)
+    x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c, seed=n)
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p, seed=1) if p > 0 else None
+    kw = dict(dropout=p, mask=mask, training=p > 0)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for exact in (True, False):
+        xin = x.bfloat16().float() if exact else x
+        ref_out, ref_g = O.gatconv_grads_autograd(xin, ei, w, a_s, a_d, b, h, c, go, **kw)
+        conv = GATConv(f, c, heads=h, dropout=p, input_aggregation=True,
+                       feature_dtype=torch.bfloat16).to(cuda).train(p > 0)
+        with torch.no_grad():
+            conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
+        conv.injected_mask = mask
+        _lib.prof_read(); _lib.prof_enable(True)
+        out = conv(xin.to(cuda), ei.to(cuda))
+        out.backward(go.to(cuda))
+        torch.cuda.synchronize(); _lib.prof_enable(False)
+        tags = {t for t, _ in _lib.prof_read()}
+        assert {"inagg_table16", "inagg_fwd", "inagg_bwd_edge"} <= tags, tags
+        grads = dict(weight=conv.lin.weight.grad, att_src=conv.att_src.grad, att_dst=conv.att_dst.grad,
+                     bias=conv.bias.grad)
+        if exact:
+            close(out, ref_out, "out")
+            for k in grads:
+                close(grads[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+        else:
+            check_bf16_tolerance(out, grads, ref_out, ref_g)
+
+
+def test_bf16_source_rows_are_refused_where_not_covered(cuda):
+    from gat_amd import GATConv, _lib, ops
+    assert not ops.inagg_rows16_supported(25, 8, 30) and not ops.inagg_rows16_supported(120, 4, 64)
+    ei, n = cases.knn_graph(n=300, f=6, seed=2)
+    conv = GATConv(25, 30, heads=8, input_aggregation=True, feature_dtype=torch.bfloat16).to(cuda).eval()
+    _lib.prof_read(); _lib.prof_enable(True)
+    conv(torch.randn(n, 25, device=cuda), ei.to(cuda))
+    torch.cuda.synchronize(); _lib.prof_enable(False)
+    assert "inagg_table16" not in {t for t, _ in _lib.prof_read()}       # f32 rows, as before

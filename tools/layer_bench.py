@@ -15,11 +15,13 @@ ap.add_argument("--dx", action="store_true", help="x carries a gradient (hidden 
 ap.add_argument("--dropout", type=float, default=0.425)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--bf16", action="store_true", help="feature_dtype=torch.bfloat16 (bf16 rows for the gathers where covered)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ei, n, _, _, _ = synth.workload_graph(a.graph, 0, dev, a.scale)
 torch.manual_seed(0)
-conv = GATConv(a.f, a.channels, heads=a.heads, dropout=a.dropout).to(dev).train()
+conv = GATConv(a.f, a.channels, heads=a.heads, dropout=a.dropout,
+               feature_dtype=torch.bfloat16 if a.bf16 else None).to(dev).train()
 x = torch.randn(n, a.f, device=dev, requires_grad=a.dx)
 go = torch.randn(n, a.heads * a.channels, device=dev)
 
@@ -42,5 +44,5 @@ _lib.prof_enable(False)
 per = {}
 for tag, v in _lib.prof_read():
     per.setdefault(tag, []).append(v)
-print(f"{a.graph} x{a.scale}: {a.f} -> {a.heads}x{a.channels}{' +d_x' if a.dx else ''}: {ms:.3f} ms/step",
+print(f"{a.graph} x{a.scale}: {a.f} -> {a.heads}x{a.channels}{' +d_x' if a.dx else ''}{' bf16' if a.bf16 else ''}: {ms:.3f} ms/step",
       {k: round(sum(v) / len(v), 3) for k, v in per.items()})
