@@ -215,6 +215,28 @@ def main():
                     "ms_per_step": round(head["ms_per_step"] + 2 * h16["ms_per_step"], 4),
                     "edges_per_s_per_layer": 3 * ep / ((head["ms_per_step"] + 2 * h16["ms_per_step"]) * 1e-3),
                     "note": "f32 input layer + two bf16 hidden layers"}
+            # and the input layer itself on bf16 source rows (gatmi_inagg_table16): same rule
+            i16 = measure_layer(args.workload, args, dev, dtype="bf16")
+            if i16["dtype"] == "bf16" and "inagg_table16" in i16["avg"]:
+                di = max(i16["kb"], key=lambda k: i16["avg"].get(k, 0.0))
+                ai = i16["kb"][di] / (i16["avg"][di] * 1e-3) / 1e9
+                res["input_layer_bf16"] = {
+                    "dtype": "bf16", "workload": i16["text"], "ms_per_step": round(i16["ms_per_step"], 4),
+                    "value": ep / (i16["ms_per_step"] * 1e-3), "unit": "edges/s",
+                    "path": "input-side aggregation on bf16 copies of the packed x rows (256-byte rows: two "
+                            "128-byte lines per edge instead of four); logits, softmax, Z, q and outputs f32",
+                    "roofline": {"bound": "hbm", "kernel": di, "achieved": round(ai, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(ai / HBM_PEAK_GBS, 4),
+                                 "avg_ms": round(i16["avg"][di], 4), "algorithmic_bytes": i16["kb"][di],
+                                 "traffic": None},
+                    "kernels": kernel_table(i16["avg"], i16["kb"]),
+                    "tolerance": "out 1e-2 max-norm, d_W 5e-2 relative L2 against the f32 oracle; the f32 bar "
+                                 "when x is bf16-exact (tests/test_gpu_bf16.py)"}
+                if "hidden_layer_bf16" in res:
+                    tot16 = i16["ms_per_step"] + 2 * res["hidden_layer_bf16"]["ms_per_step"]
+                    res["model_sum_bf16"] = {"ms_per_step": round(tot16, 4),
+                                             "edges_per_s_per_layer": 3 * ep / (tot16 * 1e-3),
+                                             "note": "bf16 input layer + two bf16 hidden layers"}
         total_ms = head["ms_per_step"] + 2 * hid["ms_per_step"]
         res["model_sum"] = {
             "layers": [f"{f}->{h}x{c} (input, no d_x)", f"{hid['f']}->{hid['h']}x{hid['c']} (hidden, d_x)",
@@ -315,7 +337,7 @@ def measure_layer(workload, args, dev, dtype=None):
     text = (f"{workload}-shaped synthetic graph: {n} nodes, {ei.size(1)} edges ({ep} after self-loop "
             f"normalisation), one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
             f"attention dropout {args.dropout} (train mode)")
-    ran_bf16 = "proj16_fwd_gemm" in avg
+    ran_bf16 = "proj16_fwd_gemm" in avg or "inagg_table16" in avg
     res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, dtype="bf16" if ran_bf16 else "f32",
                kb=kernel_bytes(n, ep, h, d, f, feat_bytes=2 if ran_bf16 else 4),
                ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text, graph_ms=graph_ms)

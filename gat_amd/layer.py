@@ -112,9 +112,11 @@ class GATConv(nn.Module):
         # streaming kernel / the register pipeline (tests, A/B runs)
         self.stream = stream
         # torch.bfloat16: on the projected-row path keep the projected rows as a bf16 table and run
-        # the projection on the bf16 matrix cores (f32 accumulation, f32 softmax and sums; the
-        # tolerance is stated separately: tests/test_gpu_bf16.py).  Shapes the bf16 kernels do not
-        # cover (ops.project_bf16_supported) and the input-side path run in f32 as before.
+        # the projection on the bf16 matrix cores (f32 accumulation, f32 softmax and sums); on the
+        # input-side path the edge kernels gather a bf16 copy of the packed x rows (logits, Z, q and
+        # outputs f32).  The tolerance is stated separately: tests/test_gpu_bf16.py.  Shapes the
+        # bf16 kernels do not cover (ops.project_bf16_supported, ops.inagg_rows16_supported) run
+        # in f32 as before.
         if feature_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError(f"feature_dtype must be None, torch.float32 or torch.bfloat16, got {feature_dtype}")
         self.feature_dtype = feature_dtype

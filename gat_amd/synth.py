@@ -70,6 +70,7 @@ def kernel_bytes(n, e, h, d, f, feat_bytes=4):
     writes d_u (4H); per node it reads h, writes d_h and d_a_src."""
     fp = (f + 3) // 4 * 4
     fs = fp + (h + 3) // 4 * 4        # packed source row: x | a_src
+    rowb = feat_bytes * fp + 4 * (fs - fp)
     return {
         # feat_bytes = 2: bf16 feature tables -- the gathered rows (h in the forward, the bf16 copy
         # of grad_out in the backward) and the row-local h are half as wide; out, d_h, a_src stay f32
@@ -79,6 +80,8 @@ def kernel_bytes(n, e, h, d, f, feat_bytes=4):
         # x | a_src (4 Fs bytes) and its col index; a node reads rowptr and a_dst, writes Z [H, Fp]
         # and lse (forward); reads its own packed row, q and Z [H, Fp], a_dst and lse (backward;
         # nothing is written per edge or per node)
-        "inagg_fwd": e * (4 * fs + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h),
-        "inagg_bwd_edge": e * (4 * fs + 4) + n * (4 + 4 * fs + 8 * h * fp + 8 * h),
+        # feat_bytes = 2: the gathered row is the bf16 copy (2 Fp bytes of x + the f32 logits); the
+        # row-local reads and Z, q stay f32
+        "inagg_fwd": e * (rowb + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h),
+        "inagg_bwd_edge": e * (rowb + 4) + n * (4 + 4 * fs + 8 * h * fp + 8 * h),
     }
