@@ -220,6 +220,7 @@ def main():
             if i16["dtype"] == "bf16" and "inagg_table16" in i16["avg"]:
                 di = max(i16["kb"], key=lambda k: i16["avg"].get(k, 0.0))
                 ai = i16["kb"][di] / (i16["avg"][di] * 1e-3) / 1e9
+                ti, tisrc = measured_traffic(args.workload, di + "_bf16")
                 res["input_layer_bf16"] = {
                     "dtype": "bf16", "workload": i16["text"], "ms_per_step": round(i16["ms_per_step"], 4),
                     "value": ep / (i16["ms_per_step"] * 1e-3), "unit": "edges/s",
@@ -228,7 +229,7 @@ def main():
                     "roofline": {"bound": "hbm", "kernel": di, "achieved": round(ai, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(ai / HBM_PEAK_GBS, 4),
                                  "avg_ms": round(i16["avg"][di], 4), "algorithmic_bytes": i16["kb"][di],
-                                 "traffic": None},
+                                 "traffic": ti, "traffic_source": tisrc},
                     "kernels": kernel_table(i16["avg"], i16["kb"]),
                     "tolerance": "out 1e-2 max-norm, d_W 5e-2 relative L2 against the f32 oracle; the f32 bar "
                                  "when x is bf16-exact (tests/test_gpu_bf16.py)"}

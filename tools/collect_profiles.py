@@ -55,6 +55,7 @@ def main():
     open(os.path.join(dst, f"pmc_{prefix}.txt"), "w").write("\n".join(lines) + "\n")
     tags = {"inagg_fwd": ["inagg_fwd_stream_kernel", "inagg_fwd3_kernel", "inagg_fwd_kernel"], "inagg_bwd_edge": ["inagg_bwd3_kernel", "inagg_bwd2_kernel", "inagg_bwd_kernel"],
             "attn_fwd": ["attn_fwd_kernel"], "attn_bwd_edge": ["attn_bwd_edge2_kernel", "attn_bwd_edge_kernel"],
+            "inagg_fwd_bf16": ["inagg_fwd16_kernel"], "inagg_bwd_edge_bf16": ["inagg_bwd16_kernel"],
             "attn_fwd_bf16": ["attn_fwd_kernel_bf16"],
             "attn_bwd_edge_bf16": ["attn_bwd_edge2_kernel_bf16", "attn_bwd_edge_kernel_bf16"]}
     old = {}
