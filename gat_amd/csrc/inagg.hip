@@ -1142,8 +1142,20 @@ template <int OP, int LOW> __device__ __forceinline__ float high_lanes_reduce(fl
     return v;
 }
 
-template <int LRL, int HPL, int U>
+// B16: the gathered rows come from the bf16 table (gatmi_inagg.xs16, laid out further down): a lane's
+// piece is 8 bytes = the same 4 channels, widened to f32; the logits sit at byte 224 of a 256-byte row.
+__device__ __forceinline__ f4 widen4(const uint2 r) {
+    return f4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+              __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+template <bool B16> struct EdgeRow { typedef f4 raw; };
+template <> struct EdgeRow<true> { typedef uint2 raw; };
+__device__ __forceinline__ f4 edge_widen(const f4 v) { return v; }
+__device__ __forceinline__ f4 edge_widen(const uint2 v) { return widen4(v); }
+
+template <int LRL, int HPL, int U, bool B16 = false>
 __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_kernel(const InArgs A) {
+    typedef typename EdgeRow<B16>::raw RAWV;
     const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, ROWF = HP * LR * 4, EPP = 64 >> HPL;
     __shared__ f2 cs_all[4][64 * HP];
@@ -1154,10 +1166,11 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
     const bool hlok = hl_raw < A.H;
     const int hl = hlok ? hl_raw : 0;
     const bool pok = p < A.lph;
-    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const unsigned offp = pok ? (unsigned)p * (B16 ? 8u : 16u) : 0u;
     const int HF = A.H * A.Fp;
-    const size_t row_bytes = (size_t)A.Fs * 4;
-    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    const size_t row_bytes = B16 ? (size_t)256 : (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(B16 ? A.xs16 : (const void *)A.xs);
+    const size_t logit_off = B16 ? (size_t)224 : (size_t)A.Fp * 4;
     f2 *cs = cs_all[wv];                                         // [edge of the chunk][HP heads]
     const unsigned hbit = 1u << hl;
     float *ydl = yd_all[wv];
@@ -1193,14 +1206,14 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
             const int cl = min(lane, n - 1);
             const int cj = A.col[c + cl];
             const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
-            auto load = [&](f4(&v)[U], int k0) {
+            auto load = [&](RAWV(&v)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = __shfl(cj, min(k0 + EP * u + eg, n - 1), 64);
-                    v[u] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                    v[u] = *reinterpret_cast<const RAWV *>(xsb + (size_t)j * row_bytes + offp);
                 }
             };
-            f4 va[U], vb[U];
+            RAWV va[U], vb[U];
             load(va, 0);
             // the chain, one (edge, head) pair per lane: edge = EPP * pass + lane / HP, head = hl
             for (int e0 = 0; e0 < n; e0 += EPP) {
@@ -1208,22 +1221,23 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
                 const int ec = min(e, n - 1);
                 const int js = __shfl(cj, ec, 64);
                 const unsigned sb = (unsigned)__shfl(kb, ec, 64);
-                const float as = A.xs[(size_t)js * A.Fs + A.Fp + hl];
+                const float as = *reinterpret_cast<const float *>(xsb + (size_t)js * row_bytes + logit_off + 4 * hl);
                 const float uu = as + adi;
                 const float slope = uu > 0.f ? 1.0f : A.neg_slope;
                 const float alpha = (e < n && hlok) ? exp_fast(uu * slope - lse_i) : 0.f;
                 const float at = (sb & hbit) ? alpha * A.inv_keep : 0.f;
                 cs[e * HP + hl_raw] = f2{at * slope, -alpha * S * slope};
             }
-            auto reduce = [&](const f4(&v)[U], int k0) {
+            auto reduce = [&](const RAWV(&raw)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int ke = k0 + EP * u + eg;              // this lane group's edge
+                    const f4 vu = edge_widen(raw[u]);
                     float dv[HP];
 #pragma unroll
                     for (int h = 0; h < HP; ++h) {
                         f2 d = {0.f, 0.f};
-                        pk_dot4(d, v[u], q4[h]);
+                        pk_dot4(d, vu, q4[h]);
                         dv[h] = d.x + d.y;
                     }
                     const float d2 = heads_sum_e<HPL, LRL>(dv, lane);
@@ -1231,7 +1245,7 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
                     const float du = ke < n ? fmaf(d2, cc.x, cc.y) : 0.f;
                     dad += du;
 #pragma unroll
-                    for (int h = 0; h < HP; ++h) pk_fma4(ys[h], bcast_head<HPL>(du, h), v[u]);
+                    for (int h = 0; h < HP; ++h) pk_fma4(ys[h], bcast_head<HPL>(du, h), vu);
                 }
             };
             for (int k0 = 0; k0 < n; k0 += 2 * U * EP) {
@@ -1277,8 +1291,9 @@ __global__ __launch_bounds__(256, HPL == 3 ? GATMI_E8_OCC : 4) void inagg_bwde_k
     }
 }
 
-template <int LRL, int HPL, int U>
+template <int LRL, int HPL, int U, bool B16 = false>
 __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
+    typedef typename EdgeRow<B16>::raw RAWV;
     const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
     constexpr int HP = 1 << HPL, LR = 1 << LRL, EP = 64 >> LRL, EPP = 64 >> HPL;
     __shared__ __attribute__((aligned(16))) float ws_all[4][64 * HP];
@@ -1287,10 +1302,11 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
     const bool hlok = hl_raw < A.H;
     const int hl = hlok ? hl_raw : 0;
     const bool pok = p < A.lph;
-    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const unsigned offp = pok ? (unsigned)p * (B16 ? 8u : 16u) : 0u;
     const int HF = A.H * A.Fp;
-    const size_t row_bytes = (size_t)A.Fs * 4;
-    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    const size_t row_bytes = B16 ? (size_t)256 : (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(B16 ? A.xs16 : (const void *)A.xs);
+    const size_t logit_off = B16 ? (size_t)224 : (size_t)A.Fp * 4;
     float *wt = ws_all[wv];                                      // [edge of the chunk][HP heads]
     const unsigned hbit = 1u << hl;
     const int stride = gridDim.x * 4;
@@ -1310,14 +1326,14 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
             const int cl = min(lane, n - 1);
             const int cj = A.col[c + cl];
             const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
-            auto load = [&](f4(&v)[U], int k0) {
+            auto load = [&](RAWV(&v)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = __shfl(cj, min(k0 + EP * u + eg, n - 1), 64);
-                    v[u] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                    v[u] = *reinterpret_cast<const RAWV *>(xsb + (size_t)j * row_bytes + offp);
                 }
             };
-            f4 va[U], vb[U];
+            RAWV va[U], vb[U];
             load(va, 0);
             // logits of the chunk, one (edge, head) pair per lane and pass
             float zz[HP];
@@ -1328,7 +1344,8 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
                 zz[ps] = -INFINITY;
                 if (EPP * ps < n) {                               // wave-uniform
                     const int js = __shfl(cj, min(e, n - 1), 64);
-                    const float uu = A.xs[(size_t)js * A.Fs + A.Fp + hl] + adi;
+                    const float uu = *reinterpret_cast<const float *>(xsb + (size_t)js * row_bytes + logit_off +
+                                                                      4 * hl) + adi;
                     zz[ps] = e < n ? (uu > 0.f ? uu : A.neg_slope * uu) : -INFINITY;
                 }
                 zmax = fmaxf(zmax, zz[ps]);
@@ -1350,19 +1367,20 @@ __global__ __launch_bounds__(256, 4) void inagg_fwde_kernel(const InArgs A) {
             m = mn;
 #pragma unroll
             for (int h = 0; h < HP; ++h) pk_scale4(acc[h], bcast_head<HPL>(sc, h));
-            auto reduce = [&](const f4(&v)[U], int k0) {
+            auto reduce = [&](const RAWV(&raw)[U], int k0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int ke = k0 + EP * u + eg;
+                    const f4 vu = edge_widen(raw[u]);
                     const float *wp = wt + min(ke, n - 1) * HP;
 #pragma unroll
                     for (int hq = 0; hq < HP / 4; ++hq) {
                         f4 w4 = *reinterpret_cast<const f4 *>(wp + 4 * hq);
                         if (ke >= n) w4 = zero4();
-                        pk_fma4(acc[4 * hq + 0], w4[0], v[u]);
-                        pk_fma4(acc[4 * hq + 1], w4[1], v[u]);
-                        pk_fma4(acc[4 * hq + 2], w4[2], v[u]);
-                        pk_fma4(acc[4 * hq + 3], w4[3], v[u]);
+                        pk_fma4(acc[4 * hq + 0], w4[0], vu);
+                        pk_fma4(acc[4 * hq + 1], w4[1], vu);
+                        pk_fma4(acc[4 * hq + 2], w4[2], vu);
+                        pk_fma4(acc[4 * hq + 3], w4[3], vu);
                     }
                 }
             };
@@ -1442,10 +1460,11 @@ __global__ __launch_bounds__(256) void inagg_table16_kernel(const float *xs, lon
             const f4 hi = 8 * p + 4 < Fp ? ldv4(r + 8 * p + 4) : zero4();
             o = make_uint4(pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]),
                            pack_bf16(hi[2], hi[3]));
-        } else if (p == 14) {
+        } else {                      // pieces 14, 15: logits of heads 0..3, 4..7
+            const int h0 = 4 * (p - 14);
             float a[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = k < H ? r[Fp + k] : 0.f;
+            for (int k = 0; k < 4; ++k) a[k] = h0 + k < H ? r[Fp + h0 + k] : 0.f;
             o = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]),
                            __float_as_uint(a[3]));
         }
@@ -2541,8 +2560,27 @@ static bool stream_ok(const InGeo &g, int H, long long num_src, int mode) {
     return num_src * g.Fs * 4 > (256ll << 20);
 }
 
-// bf16 source rows (gatmi_inagg.xs16): up to four heads, rows of at most 14 pieces of 8 channels
-static bool rows16_cover(const InGeo &g, int H) { return g.G == 64 && H <= 4 && g.Fp <= 112; }
+// bf16 source rows (gatmi_inagg.xs16): rows of at most 112 channels; up to four heads on the
+// four-edge kernels (inagg_fwd16 / inagg_bwd16), 5..8 heads on the multi-edge kernels reading 8-byte
+// pieces (rows of 9..28 float4: 4 or 2 edges per instruction)
+static bool rows16_cover(const InGeo &g, int H) {
+    if (g.G != 64 || g.Fp > 112) return false;
+    if (H <= 4) return true;
+    return g.H2 == 8 && g.lph > 8;
+}
+static void rows16_launch(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
+    if (A.H <= 4) {
+        // forward: two instructions of four edges per bank (one: 5.3 ms, three: 5.9 ms at products size)
+        if (k == IN_FWD) hipLaunchKernelGGL(inagg_fwd16_kernel<2>, dim3(grid), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(inagg_bwd16_kernel<GATMI_B16_U>, dim3(grid), dim3(256), 0, st, A);
+    } else if (g.lph > 16) {
+        if (k == IN_FWD) hipLaunchKernelGGL((inagg_fwde_kernel<5, 3, GATMI_E8_UF, true>), dim3(grid), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((inagg_bwde_kernel<5, 3, GATMI_E8_UB, true>), dim3(grid), dim3(256), 0, st, A);
+    } else {
+        if (k == IN_FWD) hipLaunchKernelGGL((inagg_fwde_kernel<4, 3, 2, true>), dim3(grid), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((inagg_bwde_kernel<4, 3, 2, true>), dim3(grid), dim3(256), 0, st, A);
+    }
+}
 
 // Persistent grid: as many blocks as fit on the device at once; chunks come from the queue.
 template <class K> static int resident_blocks(K kernel) {
@@ -2616,7 +2654,7 @@ static int check_inagg(const gatmi_graph *g, const gatmi_inagg *a, InGeo *geo) {
     GATMI_REQUIRE(a->xs && a->a_dst && a->weight && a->att_src && a->att_dst,
                   "null xs/a_dst/weight/att_src/att_dst");
     GATMI_REQUIRE(!a->xs16 || rows16_cover(*geo, a->shape.heads),
-                  "bf16 source rows cover H <= 4 and F <= 112 (got F=%d H=%d)", a->shape.in_features,
+                  "bf16 source rows cover F <= 112 with H <= 4, or 5..8 heads and F > 32 (got F=%d H=%d)", a->shape.in_features,
                   a->shape.heads);
     return GATMI_OK;
 }
@@ -2790,7 +2828,7 @@ extern "C" int gatmi_inagg_table16(const gatmi_shape *s, const float *xs, void *
     GATMI_REQUIRE(s && xs && xs16, "null shape/xs/xs16");
     InGeo g;
     GATMI_REQUIRE(make_in_geo(*s, &g) && rows16_cover(g, s->heads),
-                  "bf16 source rows cover H <= 4 and F <= 112 (got F=%d H=%d)", s->in_features, s->heads);
+                  "bf16 source rows cover F <= 112 with H <= 4, or 5..8 heads and F > 32 (got F=%d H=%d)", s->in_features, s->heads);
     if (s->num_nodes == 0) return GATMI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope ps("inagg_table16", st);
@@ -2846,8 +2884,7 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
         // picks the two-edge layout when it covers the shape (H <= 4), the head-group kernel if not
         if (a->xs16) {
             if (A.n_items > 0) {
-                                // two instructions of four edges per bank (one: 5.3 ms, three: 5.9 ms at products size)
-                hipLaunchKernelGGL(inagg_fwd16_kernel<2>, dim3(in_grid(geo, A.n_items)), dim3(256), 0, st, A);
+                rows16_launch(IN_FWD, geo, A, in_grid(geo, A.n_items), st);
                 GATMI_HIP(hipGetLastError());
             }
         } else if (stream_ok(geo, H, g->num_src, a->stream)) {
@@ -2991,7 +3028,7 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         if (A.n_items == 0) {
             GATMI_HIP(hipMemsetAsync(w.part_y, 0, (size_t)w.waves * 2 * geo.HF * 4, st));
         } else if (a->xs16) {
-            hipLaunchKernelGGL(inagg_bwd16_kernel<GATMI_B16_U>, dim3(grid), dim3(256), 0, st, A);
+            rows16_launch(IN_BWD, geo, A, grid, st);
             GATMI_HIP(hipGetLastError());
         } else if (int e = in_launch_rows(IN_BWD, geo, A, grid, st)) {
             return e;

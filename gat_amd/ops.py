@@ -236,7 +236,8 @@ def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, head
 
 
 def inagg_rows16_supported(in_features: int, heads: int, channels: int) -> bool:
-    """bf16 source rows for the input-side gathers: H <= 4, F <= 112 (inagg.hip rows16_cover)."""
+    """bf16 source rows for the input-side gathers: F <= 112 and H <= 4, or 5..8 heads with F > 32
+    (inagg.hip rows16_cover)."""
     shape = _lib.Shape(0, in_features, heads, channels)
     return int(_lib.lib().gatmi_inagg_xs16_bytes(C.byref(shape))) > 0
 

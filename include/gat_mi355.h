@@ -271,7 +271,7 @@ int gatmi_inagg_pack(const gatmi_shape *s /* num_nodes = rows to pack */, const 
 /* bf16 source rows for the gathers of this path (no counterpart in the reference; the "bf16"
  * of BASELINE.json's north_star applied to the gathered table of model.py:40's layer; tolerance
  * stated in tests/test_gpu_bf16.py).  gatmi_inagg_xs16_bytes: bytes per row (256), 0 when the
- * shape is not covered (H <= 4, F <= 112).  gatmi_inagg_table16: xs [num_nodes, Fs] -> xs16. */
+ * shape is not covered (F <= 112; H <= 4, or 5..8 heads with F > 32).  gatmi_inagg_table16: xs [num_nodes, Fs] -> xs16. */
 size_t gatmi_inagg_xs16_bytes(const gatmi_shape *s);
 int gatmi_inagg_table16(const gatmi_shape *s /* num_nodes = rows */, const float *xs, void *xs16,
                         void *stream);

@@ -261,7 +261,8 @@ def test_bf16_tables_are_refused_for_narrow_rows(cuda):
 
 @pytest.mark.parametrize("kind", ["powerlaw", "knn5", "star"])
 @pytest.mark.parametrize("n,f,h,c,p", [(3001, 100, 4, 64, 0.0), (3001, 100, 4, 64, 0.4), (2049, 112, 2, 128, 0.3),
-                                       (1500, 40, 3, 24, 0.0), (900, 108, 4, 40, 0.25)])
+                                       (1500, 40, 3, 24, 0.0), (900, 108, 4, 40, 0.25), (2049, 100, 8, 32, 0.3),
+                                       (1500, 48, 6, 20, 0.0)])
 def test_input_side_path_on_bf16_source_rows(cuda, kind, n, f, h, c, p):
     """GATConv(feature_dtype=torch.bfloat16) on the input-side aggregation path (x is data: no d_x):
     the edge kernels gather a bf16 copy of the packed x rows (gatmi_inagg_table16, 256-byte rows); the
