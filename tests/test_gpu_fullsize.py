@@ -240,3 +240,31 @@ def test_split_projection_beyond_four_gib(cuda):
     finally:
         _lib.set_option("GATMI_SPLIT3", -1)
     assert float((d_w - d_w0).abs().max()) <= 2e-5 * float(d_w0.abs().max())
+
+
+def test_full_size_bf16_source_rows(cuda, full):
+    """The input layer on bf16 source rows at full size (627 MB table, 64 M gathers of 256-byte rows):
+    an x that bf16 holds exactly gives the f32 kernels' results up to re-association; any x stays
+    inside the stated bf16 tolerance of tests/test_gpu_bf16.py against the f32 kernels."""
+    from gat_amd import GATConv
+    ei, n, f, h, c, layout = full
+    g = torch.Generator(device=cuda).manual_seed(11)
+    go = torch.randn(n, h * c, generator=g, device=cuda)
+    for exact in (True, False):
+        x = torch.randn(n, f, generator=g, device=cuda)
+        if exact:
+            x = x.bfloat16().float()
+        res = []
+        for dt in (None, torch.bfloat16):
+            torch.manual_seed(5)
+            conv = GATConv(f, c, heads=h, dropout=0.0, input_aggregation=True, feature_dtype=dt).to(cuda)
+            out = conv(x, ei)
+            out.backward(go)
+            res.append((out.detach(), conv.lin.weight.grad.clone(), conv.att_src.grad.clone(), conv.bias.grad.clone()))
+        (o32, w32, a32, b32), (o16, w16, a16, b16) = res
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+        l2 = lambda a, b: float((a - b).norm() / b.norm())
+        if exact:
+            assert rel(o16, o32) < 1e-5 and rel(w16, w32) < 2e-4 and rel(b16, b32) < 1e-5, (rel(o16, o32), rel(w16, w32))
+        else:
+            assert rel(o16, o32) < 1e-2 and l2(w16, w32) < 5e-2 and l2(a16, a32) < 2.5e-1 and rel(b16, b32) < 1e-5
