@@ -276,13 +276,22 @@ class HipBackend:
         from . import ops
         return ops.inagg_pack(x, w, att_s, att_d, cfg.heads, cfg.channels)
 
-    def inagg_fwd(self, layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, need_lse):
+    def inagg_fwd(self, layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, need_lse, xs16=None):
         from . import ops
-        return ops.inagg_fwd(layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, need_lse)
+        return ops.inagg_fwd(layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, need_lse, xs16)
 
-    def inagg_bwd(self, layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, z, lse, grad_out):
+    def inagg_bwd(self, layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, z, lse, grad_out, xs16=None):
         from . import ops
-        return ops.inagg_bwd(layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, z, lse, grad_out)
+        return ops.inagg_bwd(layout, cfg, xs_full, a_dst, w, att_s, att_d, bias, z, lse, grad_out, xs16)
+
+    # bf16 copies of the packed rows for the gathers (feature_dtype=torch.bfloat16 on exchange xs / as)
+    def inagg_rows16_supported(self, f, cfg):
+        from . import ops
+        return ops.inagg_rows16_supported(f, cfg.heads, cfg.channels)
+
+    def inagg_table16(self, table, f, cfg):
+        from . import ops
+        return ops.inagg_table16(table, f, cfg.heads, cfg.channels)
 
 
 def _pad_rows(t: Tensor, rows: int) -> Tensor:
@@ -382,19 +391,36 @@ class _PartitionedInAggFn(torch.autograd.Function):
                                          part.world, group)
                 cache["table"][:, c0:c0 + cn] = logits
             table = cache["table"]
+        # bf16 copy of the table for the edge kernels' gathers (cfg.rows16).  Exchange "as": its x
+        # pieces are as static as the f32 table's, so it is made once per x tensor and only the
+        # logits (f32, bytes 224.. of a 256-byte row = columns 56.. of the row seen as float32) are
+        # rewritten per step; exchange "xs": converted per step from the gathered rows.
+        xs16 = None
+        if getattr(cfg, "rows16", False):
+            if exchange == "as" and hit and cache.get("table16") is not None:
+                xs16 = cache["table16"]
+                xs16.view(torch.float32)[:, 56:56 + cn] = logits
+            else:
+                xs16 = be.inagg_table16(table, x_local.size(1), cfg)
+                if exchange == "as":
+                    cache["table16"] = xs16
+        elif exchange == "as":
+            cache["table16"] = None
         need_grad = any(ctx.needs_input_grad[1:5])
-        out, z, lse = be.inagg_fwd(layout, cfg, table, a_dst, weight, att_s, att_d, bias_c, need_grad)
+        kw = {} if xs16 is None else {"xs16": xs16}
+        out, z, lse = be.inagg_fwd(layout, cfg, table, a_dst, weight, att_s, att_d, bias_c, need_grad, **kw)
         if need_grad:
-            ctx.save_for_backward(table, a_dst, weight, att_s, att_d, bias_c, z, lse)
+            ctx.save_for_backward(table, a_dst, weight, att_s, att_d, bias_c, z, lse, xs16)
             ctx.misc = (layout, cfg, be, group, att_src.shape)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        table, a_dst, weight, att_s, att_d, bias_c, z, lse = ctx.saved_tensors
+        table, a_dst, weight, att_s, att_d, bias_c, z, lse, xs16 = ctx.saved_tensors
         layout, cfg, be, group, att_shape = ctx.misc
+        kw = {} if xs16 is None else {"xs16": xs16}
         d_w, d_as, d_ad, d_b = be.inagg_bwd(layout, cfg, table, a_dst, weight, att_s, att_d, bias_c,
-                                            z, lse, grad_out.contiguous())
+                                            z, lse, grad_out.contiguous(), **kw)
         all_reduce_many([d_w, d_as, d_ad, d_b], group)
         return (None, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
                 None, None, None, None, None, None, None)
@@ -414,7 +440,8 @@ class PartitionedGATConv(nn.Module):
             raise ValueError(f"balance must be 'edges' or 'nodes', got {balance!r}")
         self.balance = balance      # destination ranges of equal in-edge count / equal node count
         # torch.bfloat16: exchange "h" projects into a bf16 table, all-gathers THAT (half the xGMI
-        # volume) and gathers bf16 rows; d_h travels back in f32.  Other modes: f32.
+        # volume) and gathers bf16 rows; d_h travels back in f32.  Exchange "xs" / "as":
+        # the edge kernels gather a bf16 copy of the packed table (what travels stays f32).  "x": f32.
         self.feature_dtype = feature_dtype
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.negative_slope, self.dropout = negative_slope, dropout
@@ -465,6 +492,8 @@ class PartitionedGATConv(nn.Module):
         mode = self.resolve_exchange(x_local, cfg)
         cfg.feat_bf16 = (mode == "h" and self.feature_dtype == torch.bfloat16
                          and getattr(self.backend, "bf16_supported", lambda f, c: False)(self.in_channels, cfg))
+        cfg.rows16 = bool(mode in ("xs", "as") and self.feature_dtype == torch.bfloat16 and
+                          getattr(self.backend, "inagg_rows16_supported", lambda f, c: False)(self.in_channels, cfg))
         if mode in ("xs", "as"):
             return _PartitionedInAggFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
                                              self.bias, part, layout, cfg, self.backend,
@@ -673,7 +702,10 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
 
     elapsed, avg = _timed_steps(step, args.steps, args.warmup, dev)
     # roofline of rank 0's dominant kernel on ITS share: local destination rows, local edges
-    kb = synth.kernel_bytes(part.n_local, layout.num_edges, h, h * c, f)
+    rows16 = (getattr(args, "dtype", "f32") == "bf16" and mode in ("xs", "as")
+              and conv.backend.inagg_rows16_supported(f, AttnConfig(h, c)))
+    kb = synth.kernel_bytes(part.n_local, layout.num_edges, h, h * c, f,
+                            feat_bytes=2 if (rows16 or "proj16_fwd_gemm" in avg) else 4)
     roofline = None
     if any(k in avg for k in kb):
         dom = max(kb, key=lambda k: avg.get(k, 0.0))
@@ -695,7 +727,7 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None,
-               "dtype": "bf16" if "proj16_fwd_gemm" in avg else "f32", "data": "synthetic",
+               "dtype": "bf16" if ("proj16_fwd_gemm" in avg or rows16) else "f32", "data": "synthetic",
                "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
                                       f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
                                       f"layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "

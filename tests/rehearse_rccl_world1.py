@@ -58,18 +58,25 @@ def main():
         print(f"{'ok' if good else 'FAILED'} PartitionedGAT over RCCL: logp err {err:.2e} loss err {lerr:.2e} "
               f"worst relative grad err {gerr:.2e}", flush=True)
         # every exchange mode of one layer against the single-GPU layer
-        for mode, f, h, c, xg in (("h", 64, 4, 16, True), ("x", 12, 4, 16, True), ("xs", 12, 4, 16, False),
-                                  ("as", 12, 4, 16, False), ("h", 256, 4, 64, True)):
+        bf = torch.bfloat16
+        for mode, f, h, c, xg, dt in (("h", 64, 4, 16, True, None), ("x", 12, 4, 16, True, None),
+                                      ("xs", 12, 4, 16, False, None), ("as", 12, 4, 16, False, None),
+                                      ("h", 256, 4, 64, True, None), ("xs", 100, 4, 64, False, bf),
+                                      ("as", 100, 4, 64, False, bf), ("as", 100, 8, 32, False, bf)):
             torch.manual_seed(11)
-            one = GATConv(f, c, heads=h, dropout=0.0).to(dev)
+            # bf16 rows: both sides on the input-side path (GATConv alone would pick by a cost model)
+            one = GATConv(f, c, heads=h, dropout=0.0, feature_dtype=dt,
+                          input_aggregation=True if dt is not None else None).to(dev)
             many = PartitionedGATConv(f, c, heads=h, dropout=0.0, exchange=mode,
-                                      feature_dtype=None).to(dev)
+                                      feature_dtype=dt).to(dev)
             many.load_state_dict(one.state_dict())
             xa = torch.randn(n, f, device=dev, requires_grad=xg)
             xb = xa.detach().clone().requires_grad_(xg)
             go = torch.randn(n, h * c, device=dev)
             oa = one(xa, eid)
             oa.backward(go)
+            if dt is not None:        # a first call fills the table caches; the compared one is the second
+                many(xb, eid, n)
             ob = many(xb, eid, n)
             ob.backward(go)
             e_out = float((oa.detach() - ob.detach()).abs().max() / oa.detach().abs().max())
@@ -77,7 +84,7 @@ def main():
             e_x = float((xa.grad - xb.grad).abs().max() / xa.grad.abs().max()) if xg else 0.0
             good = e_out < 1e-5 and e_w < 1e-4 and e_x < 1e-4
             ok &= good
-            print(f"{'ok' if good else 'FAILED'} exchange={mode} {f}->{h}x{c}: out {e_out:.1e} d_W {e_w:.1e} d_x {e_x:.1e}",
+            print(f"{'ok' if good else 'FAILED'} exchange={mode} {f}->{h}x{c}{' bf16 rows' if dt is not None else ''}: out {e_out:.1e} d_W {e_w:.1e} d_x {e_x:.1e}",
                   flush=True)
         dist.barrier()
         torch.cuda.synchronize()

@@ -28,7 +28,7 @@ def test_partitioned_layer_and_network_over_rccl():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rehearse_rccl_world1.py")],
                        env=_env(29677), capture_output=True, text=True, timeout=280)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("ok", "FAILED"))]
-    assert r.returncode == 0 and len(lines) == 6 and all(ln.startswith("ok") for ln in lines), \
+    assert r.returncode == 0 and len(lines) == 9 and all(ln.startswith("ok") for ln in lines), \
         r.stdout[-2000:] + r.stderr[-2000:]
 
 
