@@ -773,6 +773,18 @@ def test_partition_kernels_match_oracle(cuda, gname, sname, world, balance):
                                                ("hub_source", "three_heads", 2), ("knn", "arxiv_l1", 4),
                                                ("multigraph", "in_odd", 3)])
 def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world, balance):
+    _partition_input_aggregation(cuda, gname, sname, world, balance, rows16=False)
+
+
+@pytest.mark.parametrize("gname,sname,world", [("star", "products_l1", 3), ("hub_source", "products_l1", 2),
+                                               ("multigraph", "hidden_8x32", 2)])
+def test_partition_input_aggregation_on_bf16_rows(cuda, gname, sname, world):
+    """The same with the edge kernels gathering the bf16 copy of the table (exchange xs / as with
+    feature_dtype=torch.bfloat16); x is bf16-exact, so the table is exact and the f32 bar holds."""
+    _partition_input_aggregation(cuda, gname, sname, world, "edges", rows16=True)
+
+
+def _partition_input_aggregation(cuda, gname, sname, world, balance, rows16):
     """Input-side aggregation in rectangular mode (what a rank of the multi-GPU layer runs):
     every rank packs its own rows, the packed table is their concatenation (the all-gather),
     the parameter gradients are the sum over ranks (the all-reduce)."""
@@ -781,6 +793,8 @@ def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world, b
     ei, n = cases.GRAPHS[gname]()
     f, h, c = cases.SHAPES[sname]
     x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c)
+    if rows16:
+        x = x.bfloat16().float()
     ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
     be = HipBackend(seg_len=64)
     cfg = ops.AttnConfig(h, c)
@@ -791,12 +805,14 @@ def test_partition_input_aggregation_matches_oracle(cuda, gname, sname, world, b
     packed = [be.inagg_pack(xd[p.lo:p.hi].contiguous(), wd, asd, add_, cfg) for p in parts]
     table = torch.cat([torch.cat([xs, xs.new_zeros(p.block - p.n_local, xs.size(1))])
                        for p, (xs, _) in zip(parts, packed)])
+    kw = {"xs16": be.inagg_table16(table, f, cfg)} if rows16 else {}
+    assert not rows16 or be.inagg_rows16_supported(f, cfg)
     outs, tot = [], None
     for p, (_, a_dst) in zip(parts, packed):
         lay = be.build_layout(local_edges(ei.to(cuda), p), p)
-        out, z, lse = be.inagg_fwd(lay, cfg, table, a_dst, wd, asd, add_, bd, True)
+        out, z, lse = be.inagg_fwd(lay, cfg, table, a_dst, wd, asd, add_, bd, True, **kw)
         outs.append(out)
-        g = be.inagg_bwd(lay, cfg, table, a_dst, wd, asd, add_, bd, z, lse, god[p.lo:p.hi].contiguous())
+        g = be.inagg_bwd(lay, cfg, table, a_dst, wd, asd, add_, bd, z, lse, god[p.lo:p.hi].contiguous(), **kw)
         tot = list(g) if tot is None else [a + b_ for a, b_ in zip(tot, g)]
     close(torch.cat(outs), ref_out, "out")
     summand = float(go.abs().max() * (x @ w.t()).abs().max())
