@@ -310,3 +310,49 @@ def test_bf16_source_rows_are_refused_where_not_covered(cuda):
     conv(torch.randn(n, 25, device=cuda), ei.to(cuda))
     torch.cuda.synchronize(); _lib.prof_enable(False)
     assert "inagg_table16" not in {t for t, _ in _lib.prof_read()}       # f32 rows, as before
+
+
+def test_random_graphs_on_bf16_source_rows(cuda):
+    """Seeded random draws (hub destinations and sources, duplicate edges, self-loops, cut rows, every
+    head count 1..8 the bf16 rows cover, odd feature counts) with a bf16-exact x: the f32 bar."""
+    import random
+    from gat_amd import GATConv, ops
+    rng = random.Random(4321)
+    done = 0
+    for trial in range(60):
+        n = rng.choice([3, 17, 64, 65, 200, 333, 1000])
+        e = rng.choice([0, n, 5 * n, 20 * n])
+        h = rng.choice([1, 2, 3, 4, 5, 6, 7, 8])
+        c = rng.choice([8, 16, 30, 33, 64])
+        f = rng.choice([33, 36, 57, 64, 65, 100, 111, 112])
+        if not ops.inagg_rows16_supported(f, h, c) or f >= h * ((c + 3) // 4 * 4):
+            continue
+        p = rng.choice([0.0, 0.3, 0.6])
+        seg = rng.choice([64, 128, 512])
+        g = torch.Generator().manual_seed(trial)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        if e > 4:
+            ei[1, : e // 3] = ei[1, 0]            # a hub destination
+            ei[0, e // 3: e // 2] = ei[0, -1]      # a hub source
+        x, w, a_s, a_d, b, go = cases.layer_inputs(n, f, h, c, seed=trial)
+        x = x.bfloat16().float()
+        ne = O.build_csr(ei, n).num_edges
+        mask = cases.keep_mask(ne, h, p, seed=trial) if p > 0 else None
+        ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p, mask=mask,
+                                                  training=p > 0)
+        conv = GATConv(f, c, heads=h, dropout=p, seg_len=seg, input_aggregation=True,
+                       feature_dtype=torch.bfloat16).to(cuda).train(p > 0)
+        with torch.no_grad():
+            conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
+        conv.injected_mask = mask
+        out = conv(x.to(cuda), ei.to(cuda))
+        out.backward(go.to(cuda))
+        summand = float(go.abs().max() * (x @ w.t()).abs().max())
+        tag = f"trial {trial} n={n} e={e} {f}->{h}x{c} p={p} seg={seg}"
+        close(out, ref_out, "out " + tag)
+        close(conv.lin.weight.grad, ref_g["weight"], "d_weight " + tag)
+        close(conv.att_src.grad, ref_g["att_src"], "d_att_src " + tag, floor=summand)
+        close(conv.att_dst.grad, ref_g["att_dst"], "d_att_dst " + tag, floor=summand)
+        close(conv.bias.grad, ref_g["bias"], "d_bias " + tag)
+        done += 1
+    assert done >= 15, done
