@@ -234,6 +234,37 @@ def test_backward_edge_pass_chain_variants(cuda, gname, sname, p, seg, hoist):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+def test_backward_edge_pass_random_graphs_full_wave_rows(cuda):
+    """Seeded random graphs (hub destinations and sources, duplicates, self-loops, cut rows, dropout)
+    on the two full-wave shapes the per-chunk chain covers, 4x64 and 8x32."""
+    import random
+    rng = random.Random(99)
+    for trial in range(24):
+        h, c = ((4, 64), (8, 32))[trial % 2]
+        n = rng.choice([2, 17, 64, 65, 200, 700])
+        e = rng.choice([0, n, 5 * n, 30 * n])
+        f = rng.choice([16, 40, 256])
+        p = rng.choice([0.0, 0.3, 0.6])
+        seg = rng.choice([64, 128, 512])
+        g = torch.Generator().manual_seed(1000 + trial)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        if e > 4:
+            ei[1, : e // 3] = ei[1, 0]
+            ei[0, e // 3: e // 2] = ei[0, -1]
+        inputs = cases.layer_inputs(n, f, h, c, seed=trial)
+        x, w, a_s, a_d, b, go = inputs
+        ne = O.build_csr(ei, n).num_edges
+        mask = cases.keep_mask(ne, h, p, seed=trial) if p > 0 else None
+        ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p, mask=mask,
+                                                  training=p > 0)
+        out, g_ = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs)
+        tag = f" trial {trial} n={n} e={e} {f}->{h}x{c} p={p} seg={seg}"
+        close(out, ref_out, "out" + tag)
+        summand = float(go.abs().max() * (x @ w.t()).abs().max())
+        for k in ref_g:
+            close(g_[k], ref_g[k], "d_" + k + tag, floor=summand if k.startswith("att") else 0.0)
+
+
 INAGG_CASES = [
     ("knn", "conv1_h30", 0.425, 512), ("knn", "products_l1", 0.425, 512), ("knn", "arxiv_l1", 0.0, 512),
     ("multigraph", "conv1_h30", 0.0, 64), ("multigraph", "products_l1", 0.3, 64),
