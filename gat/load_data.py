@@ -1,11 +1,3 @@
-"""/root/reference/gat/load_data.py:6-10 under its own import path."""
-from pathlib import Path
-
-import pandas as pd
-
-
-def load_data(file_path: Path = Path("data/traces.csv")):
-    print("Start loading data...")
-    df = pd.read_csv(file_path)
-    print("Data loaded successfully.")
-    return df
+"""The reference's CSV loader under its own import path (/root/reference/gat/load_data.py:8):
+`load_data(path)` is gat_amd.etl.read_traces."""
+from gat_amd.etl import read_traces as load_data  # noqa: F401

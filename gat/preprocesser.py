@@ -6,23 +6,16 @@ gat_amd.trials.load_xy() is used instead and says so."""
 import os
 
 from gat_amd import etl
-from gat_amd.trials import load_xy
+from gat_amd.trials import load_xy, shuffle_settings
 
 _PREPARED = "__prepared__"      # marks the stand-in table, whose columns are final already
 
 
-def _csv_path():
-    return os.environ.get("GAT_TRACES_CSV", os.path.join("data", "traces.csv"))
-
-
 def preprocess_df():
-    path = _csv_path()
+    path = etl.traces_path()
     if os.path.exists(path):
-        import pandas as pd
-        print("Start loading data...")
-        raw = pd.read_csv(path)
-        print("Data loaded successfully.")
-        return etl.preprocess_df(raw)
+        seed, chunks = shuffle_settings()
+        return etl.preprocess_df(etl.read_traces(path), num_chunks=chunks, shuffle_seed=seed)
     X, y = load_xy()     # GAT_TRACES_NPZ or the synthetic stand-in: columns are final already
     df = X.copy()
     df["is_anomaly"] = y.values

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import hashlib
 import multiprocessing as mp
+import os
 from typing import Optional
 
 import numpy as np
@@ -153,6 +154,25 @@ def construct_port_scan_label(df: pd.DataFrame, num_chunks: Optional[int] = None
     out = pd.concat(pieces, ignore_index=True) if pieces else df.assign(diversity_index=[])
     out["diversity_index"] = out["diversity_index"].fillna(0)
     return out.sample(frac=1, random_state=shuffle_seed).reset_index(drop=True)
+
+
+# ------------------------------------------------------------------ the raw table
+def traces_path() -> str:
+    """Where the raw traces are looked for: GAT_TRACES_CSV, else the reference's fixed location
+    (load_data.py:6)."""
+    return os.environ.get("GAT_TRACES_CSV", os.path.join("data", "traces.csv"))
+
+
+def read_traces(source=None, announce: bool = True) -> pd.DataFrame:
+    """The raw table as a frame (the reference's I/O step, load_data.py:8): `source` is a path, or
+    None for traces_path()."""
+    source = traces_path() if source is None else os.fspath(source)
+    if announce:
+        print(f"[gat_amd] reading raw traces from {source}")
+    frame = pd.read_csv(source)
+    if announce:
+        print(f"[gat_amd] {len(frame)} trace rows read")
+    return frame
 
 
 # ------------------------------------------------------------------ the three entry points

@@ -50,6 +50,20 @@ _XY = None
 _GRAPHS = None
 
 
+def shuffle_settings():
+    """(shuffle_seed, num_chunks) for the feature engineering.  One process: the reference's own
+    behaviour -- an unseeded shuffle, one chunk per host CPU (preprocesser.py:40-47) -- unless
+    GAT_SHUFFLE_SEED / GAT_ETL_CHUNKS say otherwise.  Several ranks: every rank prepares the table
+    itself, so both are FIXED (seed 0, 8 chunks by default) -- with an unseeded shuffle each rank
+    would train and score its trials on a differently ordered table and a different split, and the
+    scores gathered from the ranks would not be comparable (the reference evaluates every
+    configuration of a search on one split)."""
+    seed, chunks = os.environ.get("GAT_SHUFFLE_SEED"), os.environ.get("GAT_ETL_CHUNKS")
+    if world()[1] > 1:
+        return int(seed) if seed is not None else 0, int(chunks) if chunks is not None else 8
+    return (int(seed) if seed is not None else None), (int(chunks) if chunks is not None else None)
+
+
 def load_xy():
     """(X, y) once per process, as grid_search.py:42-49 caches them.  In this order: the reference's
     own input, data/traces.csv (or the file GAT_TRACES_CSV names), through the reference's feature
@@ -57,12 +71,13 @@ def load_xy():
     does not ship its CSV -- a synthetic table of the same shape, announced as such."""
     global _XY
     if _XY is None:
-        csv = os.environ.get("GAT_TRACES_CSV", os.path.join("data", "traces.csv"))
+        from . import etl
+        csv = etl.traces_path()
         path = os.environ.get("GAT_TRACES_NPZ")
         if os.path.exists(csv):
-            import pandas as pd
-            from . import etl
-            df = etl.preprocess_df(pd.read_csv(csv))
+            seed, chunks = shuffle_settings()
+            df = etl.preprocess_df(etl.read_traces(csv, announce=world()[0] == 0),
+                                   num_chunks=chunks, shuffle_seed=seed)
             _XY = (etl.preprocess_X(df), etl.preprocess_y(df))
         elif path:
             import pandas as pd

@@ -86,3 +86,37 @@ def test_drop_in_preprocesser_reads_a_csv(tmp_path, monkeypatch):
     X, y = pp.preprocess_X(df), pp.preprocess_y(df)
     assert list(X.columns) == etl.FEATURES and len(X) == (800 // os.cpu_count()) * os.cpu_count()
     assert y.dtype.kind == "i"
+
+
+_RANK_TABLE = r"""
+import hashlib, os, sys
+sys.path.insert(0, {root!r})
+from gat_amd import trials
+X, y = trials.load_xy()
+h = hashlib.sha256(X.values.tobytes() + y.values.tobytes()).hexdigest()
+print("TABLE", os.environ["RANK"], len(X), h)
+"""
+
+
+def test_every_rank_of_a_search_prepares_the_same_table(tmp_path):
+    """with data/traces.csv present every rank runs the feature engineering itself; the
+    reference's unseeded shuffle (preprocesser.py:47) would give each rank its own row order and so
+    its own train/test split.  With WORLD_SIZE > 1 the shuffle seed and the chunk count are fixed:
+    two ranks (separate processes) hold byte-identical X and y; one process alone keeps the
+    reference's unseeded shuffle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    raw = etl.synthetic_raw_traces(640, seed=11)
+    csv = tmp_path / "traces.csv"
+    raw.to_csv(csv, index=False)
+    lines = []
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", GAT_TRACES_CSV=str(csv))
+        out = subprocess.run([sys.executable, "-c", _RANK_TABLE.format(root=root)], env=env,
+                             capture_output=True, text=True, check=True, cwd=tmp_path).stdout
+        lines.append([ln for ln in out.splitlines() if ln.startswith("TABLE")][0].split())
+    assert lines[0][2] == lines[1][2] == "640"
+    assert lines[0][3] == lines[1][3], "ranks prepared different tables"
+    from gat_amd import trials
+    assert trials.shuffle_settings() == (None, None)       # one process: as the reference

@@ -85,7 +85,7 @@ def test_cora_shaped_two_layer_network(cuda):
     loss = F.nll_loss(logp, y.to(cuda))
     loss.backward()
     close(logp, ref_logp, "log-probabilities")
-    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * abs(float(ref_loss.detach()))
     for (name, pr), pg in zip(list(r1.named_parameters()) + list(r2.named_parameters()),
                               list(c1.parameters()) + list(c2.parameters())):
         # d_att_*: sums of cancelling terms, measured against one summand (as everywhere)
