@@ -48,6 +48,13 @@ class Attn(C.Structure):
                 ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class AttnPartial(C.Structure):
+    _fields_ = [("m", C.c_void_p), ("s", C.c_void_p), ("acc", C.c_void_p)]
+
+
+MAX_PARTS = 16     # GATMI_MAX_PARTS
+
+
 class InAgg(C.Structure):
     _fields_ = [("shape", Shape), ("negative_slope", C.c_float), ("dropout_p", C.c_float),
                 ("mask_mode", C.c_int32), ("stream", C.c_int32), ("seed", C.c_uint64),
@@ -99,6 +106,19 @@ SYMBOLS = {
     "gatmi_attn_bwd": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_attn_fwd_partial": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.POINTER(AttnPartial),
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_attn_fwd_combine": (C.c_int, [C.POINTER(Shape), C.c_int, C.POINTER(AttnPartial), C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gatmi_attn_bwd_node_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int, C.c_int]),
+    "gatmi_attn_bwd_chunk_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
+    "gatmi_attn_bwd_begin": (C.c_int, [C.POINTER(Attn), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_attn_bwd_chunk": (C.c_int, [C.POINTER(Graph), C.POINTER(Attn), C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_attn_bwd_end": (C.c_int, [C.POINTER(Attn), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gatmi_add_dst_term": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "gatmi_glue_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -43,6 +43,8 @@ struct RowArgs {
     float *out;
     float *lse;
     float *part_m, *part_s, *part_acc;
+    float *row_m, *row_s, *row_acc;   // source chunks: un-normalised (m, s, acc) per destination row
+                                      // instead of out / lse (NULL: the whole table is here)
     // backward edge pass (transposed CSR; hp = padded grad_out there)
     const void *hself;     // [N, Dp] projected features (row-local), same element type as hp
     const float *nodeinfo; // [N, H, 4] (a_dst, lse, S, 0)
@@ -165,7 +167,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
             reduce(vb, k0 + U);   // unconditional: keeps the prefetch out of a branch
         }
     }
-    if (slot < 0) {
+    if (slot < 0 && A.row_acc) {
+        // one source chunk of several: the row's partial triple, normalised by the combine pass
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (S.nval[t]) {
+                st4(A.row_acc + (size_t)row * A.Dp + S.poff[t], acc[t]);
+                if ((S.poff[t] % A.Cp) == 0) {
+                    A.row_m[(size_t)row * A.H + S.head[t]] = m[t];
+                    A.row_s[(size_t)row * A.H + S.head[t]] = ssum[t];
+                }
+            }
+        }
+    } else if (slot < 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const float4 bia = A.bias ? ldc(A.bias + S.coff[t], S.nval[t], vec_ok)
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
 __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
     const int *split_row, const int *split_slot, int n_split, int H, int C, int Cp, int Dp,
     const float *part_m, const float *part_s, const float *part_acc, const float *bias,
-    float *out, float *lse) {
+    float *out, float *lse, float *row_m, float *row_s, float *row_acc) {
     const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (w >= n_split) return;
     const int lane = threadIdx.x & 63;
@@ -216,6 +230,14 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
             const float f = expf(part_m[(size_t)s * H + head] - M);
             tot = fmaf(part_s[(size_t)s * H + head], f, tot);
             fma4(acc, f, ld4(part_acc + (size_t)s * Dp + head * Cp + sub * 4));
+        }
+        if (row_acc) {      // one source chunk of several: leave the merged triple un-normalised
+            st4(row_acc + (size_t)row * Dp + head * Cp + sub * 4, acc);
+            if (sub == 0) {
+                row_m[(size_t)row * H + head] = M;
+                row_s[(size_t)row * H + head] = tot;
+            }
+            continue;
         }
         const float inv = tot > 0.f ? 1.0f / tot : 0.f;
         const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -603,7 +625,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_merge_kernel(
 __global__ __launch_bounds__(256) void attn_bwd_dst_kernel(
     const int *rowptr, const int *d2s, const int *item_row, const int *item_beg,
     const int *item_slot, int n_items, int seg_len, int H, int hp2_log, const float *du_t,
-    float *da_dst, float *part_dad) {
+    float *da_dst, float *part_dad, int accumulate /* source chunks: da_dst += */) {
     const int lane = threadIdx.x & 63;
     const int hp2 = 1 << hp2_log;
     const int h = lane & (hp2 - 1), eo = lane >> hp2_log, epw = 64 >> hp2_log;
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dst_kernel(
         // sum over the lanes that share h: strides hp2, 2*hp2, ... 32 -- a fixed tree
         for (int o = hp2; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
         if (eo == 0 && h < H) {
-            if (slot < 0) da_dst[(size_t)row * H + h] = s;
+            if (slot < 0) da_dst[(size_t)row * H + h] = accumulate ? da_dst[(size_t)row * H + h] + s : s;
             else part_dad[(size_t)slot * H + h] = s;
         }
     }
@@ -625,13 +647,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dst_kernel(
 
 __global__ __launch_bounds__(256) void attn_bwd_dst_merge_kernel(
     const int *split_row, const int *split_slot, int n_split, int H, const float *part_dad,
-    float *da_dst) {
+    float *da_dst, int accumulate) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_split * H) return;
     const int w = idx / H, head = idx % H;
     float acc = 0.f;
     for (int s = split_slot[w]; s < split_slot[w + 1]; ++s) acc += part_dad[(size_t)s * H + head];
-    da_dst[(size_t)split_row[w] * H + head] = acc;
+    float *o = da_dst + (size_t)split_row[w] * H + head;
+    *o = accumulate ? *o + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------
@@ -698,7 +721,7 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(
             }
             if (r < n_dst) {
                 const float dd = da_dst[r * H + head];
-                if (!same) hv = ld_own<RAW>(hp, (size_t)(r + dst_off), Dp, slot * 4);
+                if (!same || r >= n_src) hv = ld_own<RAW>(hp, (size_t)(r + dst_off), Dp, slot * 4);
                 fma4(b, dd, hv);
                 if (dhp) {  // d_h[r] += d_a_dst[r] att_dst
                     float4 dh = ld4(dhp + (r + dst_off) * Dp + slot * 4);
@@ -995,7 +1018,8 @@ static int attn_fwd_run(const gatmi_graph *g, const gatmi_attn *a, const Geometr
         const int blocks = (g->plan.n_split_rows + 3) / 4;
         hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(blocks), dim3(256), 0, st,
                            g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H, A.C,
-                           A.Cp, A.Dp, A.part_m, A.part_s, A.part_acc, A.bias, out, lse);
+                           A.Cp, A.Dp, A.part_m, A.part_s, A.part_acc, A.bias, out, lse, A.row_m,
+                           A.row_s, A.row_acc);
         GATMI_HIP(hipGetLastError());
     }
     return GATMI_OK;
@@ -1194,13 +1218,13 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
         const int grid = item_grid(g->plan.n_items, 4);
         hipLaunchKernelGGL(attn_bwd_dst_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->d2s,
                            g->plan.item_row, g->plan.item_beg, g->plan.item_slot, g->plan.n_items,
-                           g->seg_len, H, hp2_log, w.du_t, w.da_dst, w.part_dad);
+                           g->seg_len, H, hp2_log, w.du_t, w.da_dst, w.part_dad, 0);
         GATMI_HIP(hipGetLastError());
         if (g->plan.n_split_rows > 0) {
             const int tot = g->plan.n_split_rows * H;
             hipLaunchKernelGGL(attn_bwd_dst_merge_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
                                g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, H,
-                               w.part_dad, w.da_dst);
+                               w.part_dad, w.da_dst, 0);
             GATMI_HIP(hipGetLastError());
         }
     }
@@ -1238,5 +1262,386 @@ extern "C" int gatmi_add_dst_term(const gatmi_shape *s, float *d_hp, const float
                        static_cast<hipStream_t>(stream), d_hp, d_a_dst, att_dst,
                        (long long)s->num_nodes, s->heads, s->channels, geo.Cp);
     GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Source chunks: the same layer when the feature table arrives in pieces (a pipelined
+// all-gather on a destination partition, SURVEY.md 8e "chunk the all-gather by source range").
+// Chunk k has a rectangular layout of its own -- the edges whose sources lie in the chunk,
+// sources renumbered from the chunk's first row -- and the kernels above run on it unchanged:
+//   forward   gatmi_attn_fwd_partial per chunk: the un-normalised online-softmax triple
+//             (m, s, acc) of every destination row over the chunk's edges;
+//             gatmi_attn_fwd_combine: the triples of all chunks -> out, lse (the merge of cut
+//             rows, across chunks; chunk order fixed -> bitwise reproducible)
+//   backward  gatmi_attn_bwd_begin (per-node preparation, once), gatmi_attn_bwd_chunk per chunk
+//             (edge pass over the chunk's transposed CSR -> d_h of the chunk's source rows,
+//             complete, ready for its reduce-scatter; d_a_dst accumulated), gatmi_attn_bwd_end
+//             (d_att_src, d_att_dst, d_bias).
+// ---------------------------------------------------------------------------------
+namespace gatmi {
+
+struct CombineArgs {
+    const float *m[GATMI_MAX_PARTS], *s[GATMI_MAX_PARTS], *acc[GATMI_MAX_PARTS];
+    int n_parts;
+};
+
+// One thread per float4 slot of a destination row; the per-head scalars are re-read by the
+// lanes of a head (cache hits).
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(
+    const CombineArgs P, long long total /* rows * Dp / 4 */, int H, int C, int Cp, int Dp,
+    const float *bias, float *out, float *lse) {
+    const int nslot = Dp >> 2, lph = Cp >> 2;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += gridDim.x * 256ll) {
+        const long long row = idx / nslot;
+        const int q = (int)(idx - row * nslot);
+        const int head = q / lph, sub = q - head * lph;
+        float M = -INFINITY;
+        for (int k = 0; k < P.n_parts; ++k) M = fmaxf(M, P.m[k][row * H + head]);
+        float tot = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < P.n_parts; ++k) {
+            const float mk = P.m[k][row * H + head];
+            if (mk == -INFINITY) continue;          // no edge of this row in chunk k
+            const float f = expf(mk - M);
+            tot = fmaf(P.s[k][row * H + head], f, tot);
+            fma4(acc, f, ld4(P.acc[k] + row * Dp + q * 4));
+        }
+        const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+        const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (int k = 0; k < 4; ++k) {
+            const int c = sub * 4 + k;
+            if (c < C) {
+                const float b = bias ? bias[head * C + c] : 0.f;
+                out[row * H * C + head * C + c] = fmaf(a4[k], inv, b);
+            }
+        }
+        if (lse && sub == 0) lse[row * H + head] = M + logf(tot);
+    }
+}
+
+// Checks shared by the chunk entry points: as check_attn, but a chunk's sources are a slice of
+// the table that need not hold the destination rows (dst_offset is not used).
+static int check_chunk(const gatmi_graph *g, const gatmi_attn *a) {
+    GATMI_REQUIRE(g && a, "null graph/attn descriptor");
+    GATMI_REQUIRE(g->num_dst == a->shape.num_nodes, "graph has %d destination rows, layer %d",
+                  g->num_dst, a->shape.num_nodes);
+    GATMI_REQUIRE(g->seg_len >= 64 && g->seg_len % 64 == 0, "seg_len %d must be a multiple of 64",
+                  g->seg_len);
+    GATMI_REQUIRE(a->mask_mode >= 0 && a->mask_mode <= 3, "bad mask_mode %d", a->mask_mode);
+    GATMI_REQUIRE((a->mask_mode != GATMI_MASK_BYTES && a->mask_mode != GATMI_MASK_HASH_DEV) || a->mask,
+                  "mask_mode BYTES / HASH_DEV needs `mask` (the keep flags / the device seed)");
+    GATMI_REQUIRE(a->dropout_p >= 0.f && a->dropout_p <= 1.f, "dropout_p %f outside [0,1]",
+                  a->dropout_p);
+    GATMI_REQUIRE(a->mask_mode == GATMI_MASK_NONE || a->shape.heads <= 32,
+                  "attention dropout supports at most 32 heads, got %d", a->shape.heads);
+    GATMI_REQUIRE((a->hp || g->num_src == 0) && a->a_dst && a->att_src, "null hp/a_dst/att_src");
+    GATMI_REQUIRE(!a->feat_bf16 || gatmi_attn_bf16_supported(&a->shape),
+                  "bf16 feature tables need rows of more than 32 float4 slots: got %d x %d",
+                  a->shape.heads, a->shape.channels);
+    return GATMI_OK;
+}
+
+// Per-node state of a chunked backward: what gatmi_attn_bwd keeps at the head of its workspace,
+// sized by the destination rows alone so that every chunk call finds it at the same place.
+struct NodeWs {
+    float *nodeinfo, *gp, *gsum_partial, *colsum;
+    bf16x4 *g16;
+    size_t bytes;
+};
+static NodeWs carve_node(const gatmi_shape *s, const Geometry &geo, int max_chunks, bool feat_bf16,
+                         void *ws) {
+    Carver cv(ws);
+    NodeWs w;
+    const size_t N = (size_t)s->num_nodes, H = (size_t)s->heads;
+    w.nodeinfo = cv.take<float>(N * H * 4);
+    w.gp = (!feat_bf16 && (s->channels & 3)) ? cv.take<float>(N * geo.Dp) : nullptr;
+    w.g16 = feat_bf16 ? cv.take<bf16x4>(N * geo.Dp / 4) : nullptr;
+    w.gsum_partial = cv.take<float>((size_t)kColsumBlocks * geo.Dp);
+    // column-sum partials: one [blocks, 2, Dp] slab per chunk (d_att_src) + one for d_att_dst
+    w.colsum = cv.take<float>((size_t)(max_chunks + 1) * kColsumBlocks * 2 * geo.Dp);
+    w.bytes = cv.off + 256;
+    return w;
+}
+
+struct ChunkWs {
+    float *du_t, *da_src, *part_dad, *part_das, *part_dh;
+    size_t bytes;
+};
+static ChunkWs carve_chunk(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws) {
+    Carver cv(ws);
+    ChunkWs w;
+    const size_t H = (size_t)s->heads;
+    w.du_t = cv.take<float>((size_t)g->num_edges * H);
+    w.da_src = cv.take<float>((size_t)g->num_src * H);
+    w.part_dad = cv.take<float>((size_t)g->plan.n_slots * H);
+    w.part_das = cv.take<float>((size_t)g->plan_t.n_slots * H);
+    w.part_dh = cv.take<float>((size_t)g->plan_t.n_slots * geo.Dp);
+    w.bytes = cv.off + 256;
+    return w;
+}
+
+}  // namespace gatmi
+
+extern "C" int gatmi_attn_fwd_partial(const gatmi_graph *g, const gatmi_attn *a,
+                                      const gatmi_attn_partial *p, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    if (int e = check_chunk(g, a)) return e;
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    GATMI_REQUIRE(p && p->m && p->s && p->acc, "null partial (m, s, acc)");
+    if (ws_bytes < gatmi_attn_fwd_workspace_bytes(g, &a->shape)) {
+        set_error("attn_fwd_partial workspace too small: %zu < %zu", ws_bytes,
+                  gatmi_attn_fwd_workspace_bytes(g, &a->shape));
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RowArgs A;
+    fill_common(A, *a, geo);
+    A.rowptr = g->rowptr;
+    A.col = g->col;
+    A.item_row = g->plan.item_row;
+    A.item_beg = g->plan.item_beg;
+    A.item_slot = g->plan.item_slot;
+    A.n_items = g->plan.n_items;
+    A.seg_len = g->seg_len;
+    A.row_m = p->m;
+    A.row_s = p->s;
+    A.row_acc = p->acc;
+    const size_t slots = (size_t)g->plan.n_slots;
+    Carver cv(ws);
+    A.part_m = cv.take<float>(slots * A.H);
+    A.part_s = cv.take<float>(slots * A.H);
+    A.part_acc = cv.take<float>(slots * geo.Dp);
+    {
+        ProfScope ps("attn_fwd", st);
+        if (int e = launch_rows(FWD, geo, A, st)) return e;
+    }
+    if (g->plan.n_split_rows > 0) {
+        ProfScope ps("attn_fwd_merge", st);
+        const int blocks = (g->plan.n_split_rows + 3) / 4;
+        hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(blocks), dim3(256), 0, st,
+                           g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, A.H, A.C,
+                           A.Cp, A.Dp, A.part_m, A.part_s, A.part_acc, A.bias, nullptr, nullptr,
+                           A.row_m, A.row_s, A.row_acc);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_attn_fwd_combine(const gatmi_shape *s, int n_parts,
+                                      const gatmi_attn_partial *parts, const float *bias,
+                                      float *out, float *lse, void *stream) {
+    GATMI_REQUIRE(s && parts && out, "null shape/parts/out");
+    GATMI_REQUIRE(n_parts >= 1 && n_parts <= GATMI_MAX_PARTS, "n_parts %d outside [1, %d]", n_parts,
+                  GATMI_MAX_PARTS);
+    Geometry geo;
+    if (int e = make_geometry(*s, &geo)) return e;
+    CombineArgs P;
+    memset(&P, 0, sizeof(P));
+    P.n_parts = n_parts;
+    for (int k = 0; k < n_parts; ++k) {
+        GATMI_REQUIRE(parts[k].m && parts[k].s && parts[k].acc, "null partial %d", k);
+        P.m[k] = parts[k].m;
+        P.s[k] = parts[k].s;
+        P.acc[k] = parts[k].acc;
+    }
+    const long long total = (long long)s->num_nodes * (geo.Dp / 4);
+    if (total == 0) return GATMI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps("attn_fwd_combine", st);
+    const long long want = (total + 255) / 256;
+    const int blocks = (int)(want > 16384 ? 16384 : want);
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(blocks), dim3(256), 0, st, P, total, s->heads,
+                       s->channels, geo.Cp, geo.Dp, bias, out, lse);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+extern "C" size_t gatmi_attn_bwd_node_workspace_bytes(const gatmi_shape *s, int max_chunks,
+                                                      int feat_bf16) {
+    Geometry geo;
+    if (!s || max_chunks < 1 || max_chunks > GATMI_MAX_PARTS || make_geometry(*s, &geo)) return 0;
+    return carve_node(s, geo, max_chunks, feat_bf16 != 0, nullptr).bytes;
+}
+
+extern "C" size_t gatmi_attn_bwd_chunk_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s) {
+    Geometry geo;
+    if (!g || !s || make_geometry(*s, &geo)) return 0;
+    return carve_chunk(g, s, geo, nullptr).bytes;
+}
+
+extern "C" int gatmi_attn_bwd_begin(const gatmi_attn *a, int max_chunks, const float *out,
+                                    const float *lse, const float *grad_out, void *node_ws,
+                                    size_t node_ws_bytes, void *stream) {
+    GATMI_REQUIRE(a && out && lse && grad_out && a->a_dst, "null attn/out/lse/grad_out/a_dst");
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    const bool bf = a->feat_bf16 != 0;
+    GATMI_REQUIRE(!bf || gatmi_attn_bf16_supported(&a->shape), "bf16 feature tables do not cover %d x %d",
+                  a->shape.heads, a->shape.channels);
+    const size_t need = gatmi_attn_bwd_node_workspace_bytes(&a->shape, max_chunks, bf);
+    if (need == 0 || node_ws_bytes < need) {
+        set_error("attn_bwd node workspace too small (or max_chunks %d outside [1, %d]): %zu < %zu",
+                  max_chunks, GATMI_MAX_PARTS, node_ws_bytes, need);
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    NodeWs w = carve_node(&a->shape, geo, max_chunks, bf, node_ws);
+    const int N = a->shape.num_nodes, H = a->shape.heads, C = a->shape.channels;
+    // every column-sum slab reads as zero until its chunk (or the end call) fills it: chunks a
+    // caller skips (no rows, no edges) then contribute nothing
+    GATMI_HIP(hipMemsetAsync(w.colsum, 0,
+                             (size_t)(max_chunks + 1) * kColsumBlocks * 2 * geo.Dp * sizeof(float), st));
+    if (N == 0) return GATMI_OK;
+    const int prep_blocks = N < kColsumBlocks ? N : kColsumBlocks;
+    ProfScope ps("attn_bwd_prep", st);
+    const bool flat = (C & 3) == 0 && geo.lph == geo.lph2 && geo.lph <= 64 &&
+                      ((geo.Dp / 4) & (geo.Dp / 4 - 1)) == 0 && geo.Dp / 4 <= 256;
+    if (flat)
+        hipLaunchKernelGGL(bwd_prep_flat_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
+                           a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H, geo.lph2_log,
+                           geo.Dp / 4, reinterpret_cast<float4 *>(w.nodeinfo), w.gsum_partial, w.g16);
+    else
+        hipLaunchKernelGGL(bwd_prep_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
+                           a->bias, a->a_dst, lse, N, H, C, geo.Cp, geo.Dp,
+                           reinterpret_cast<float4 *>(w.nodeinfo), w.gp, w.gsum_partial, w.g16);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_attn_bwd_chunk(const gatmi_graph *g, const gatmi_attn *a, int chunk,
+                                    int max_chunks, int accumulate, const float *grad_out,
+                                    void *node_ws, size_t node_ws_bytes, float *d_hp, float *d_a_dst,
+                                    void *ws, size_t ws_bytes, void *stream) {
+    if (int e = check_chunk(g, a)) return e;
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    GATMI_REQUIRE(grad_out && d_a_dst && (d_hp || g->num_src == 0), "null grad_out/d_a_dst/d_hp");
+    GATMI_REQUIRE(max_chunks >= 1 && max_chunks <= GATMI_MAX_PARTS && chunk >= 0 && chunk < max_chunks,
+                  "chunk %d of %d (at most %d)", chunk, max_chunks, GATMI_MAX_PARTS);
+    const bool bf = a->feat_bf16 != 0;
+    const size_t need_node = gatmi_attn_bwd_node_workspace_bytes(&a->shape, max_chunks, bf);
+    const size_t need = gatmi_attn_bwd_chunk_workspace_bytes(g, &a->shape);
+    if (node_ws_bytes < need_node || ws_bytes < need) {
+        set_error("attn_bwd_chunk workspace too small: node %zu < %zu or chunk %zu < %zu",
+                  node_ws_bytes, need_node, ws_bytes, need);
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    NodeWs nw = carve_node(&a->shape, geo, max_chunks, bf, node_ws);
+    ChunkWs w = carve_chunk(g, &a->shape, geo, ws);
+    const int N = g->num_dst, NS = g->num_src, H = a->shape.heads, C = a->shape.channels;
+    float *colsum = nw.colsum + (size_t)chunk * kColsumBlocks * 2 * geo.Dp;
+    const int cs_blocks = NS < kColsumBlocks ? NS : kColsumBlocks;
+    if (NS == 0 || N == 0) {
+        // an empty chunk contributes nothing (its column-sum slab was zeroed by the begin call);
+        // without destination rows the chunk's d_h is all zeros, and it is reduced over the ranks
+        if (N == 0 && NS > 0) GATMI_HIP(hipMemsetAsync(d_hp, 0, (size_t)NS * geo.Dp * sizeof(float), st));
+        if (!accumulate && N > 0) GATMI_HIP(hipMemsetAsync(d_a_dst, 0, (size_t)N * H * sizeof(float), st));
+        return GATMI_OK;
+    }
+    const void *gpad = nw.g16 ? static_cast<const void *>(nw.g16)
+                              : static_cast<const void *>(nw.gp ? nw.gp : grad_out);
+    RowArgs B;
+    fill_common(B, *a, geo);
+    B.hp = gpad;
+    B.hself = a->hp;
+    B.nodeinfo = nw.nodeinfo;
+    B.rowptr = g->rowptr_t;
+    B.col = g->col_t;
+    B.aux = g->pos_t;
+    B.item_row = g->plan_t.item_row;
+    B.item_beg = g->plan_t.item_beg;
+    B.item_slot = g->plan_t.item_slot;
+    B.n_items = g->plan_t.n_items;
+    B.seg_len = g->seg_len;
+    B.du_t = w.du_t;
+    B.dhp = d_hp;
+    B.da_src = w.da_src;
+    B.part_das = w.part_das;
+    B.part_dh = w.part_dh;
+    {
+        ProfScope ps("attn_bwd_edge", st);
+        if (int e = launch_rows(BWD_EDGE, geo, B, st)) return e;
+    }
+    if (g->plan_t.n_split_rows > 0) {
+        ProfScope ps("attn_bwd_edge_merge", st);
+        const int blocks = (g->plan_t.n_split_rows + 3) / 4;
+        hipLaunchKernelGGL(attn_bwd_edge_merge_kernel, dim3(blocks), dim3(256), 0, st,
+                           g->plan_t.split_row, g->plan_t.split_slot, g->plan_t.n_split_rows, H, C,
+                           geo.Cp, geo.Dp, w.part_dh, w.part_das, a->att_src, d_hp, w.da_src);
+        GATMI_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps("attn_bwd_dst", st);
+        const int hp2_log = ilog2(next_pow2(H));
+        GATMI_REQUIRE(hp2_log <= 6, "more than 64 heads");
+        const int grid = item_grid(g->plan.n_items, 4);
+        hipLaunchKernelGGL(attn_bwd_dst_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->d2s,
+                           g->plan.item_row, g->plan.item_beg, g->plan.item_slot, g->plan.n_items,
+                           g->seg_len, H, hp2_log, w.du_t, d_a_dst, w.part_dad, accumulate ? 1 : 0);
+        GATMI_HIP(hipGetLastError());
+        if (g->plan.n_split_rows > 0) {
+            const int tot = g->plan.n_split_rows * H;
+            hipLaunchKernelGGL(attn_bwd_dst_merge_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
+                               g->plan.split_row, g->plan.split_slot, g->plan.n_split_rows, H,
+                               w.part_dad, d_a_dst, accumulate ? 1 : 0);
+            GATMI_HIP(hipGetLastError());
+        }
+    }
+    {
+        // sum_j d_a_src[j] h[j] over the chunk's source rows (n_dst = 0: no destination term here)
+        ProfScope ps("param_colsum", st);
+        if (bf)
+            hipLaunchKernelGGL(colsum_stage1_kernel<bf16x4>, dim3(cs_blocks), dim3(256), 0, st, a->hp,
+                               w.da_src, d_a_dst, a->att_dst, nullptr, NS, 0, 0, H, C, geo.Cp, geo.Dp,
+                               colsum);
+        else
+            hipLaunchKernelGGL(colsum_stage1_kernel<float4>, dim3(cs_blocks), dim3(256), 0, st, a->hp,
+                               w.da_src, d_a_dst, a->att_dst, nullptr, NS, 0, 0, H, C, geo.Cp, geo.Dp,
+                               colsum);
+        GATMI_HIP(hipGetLastError());
+    }
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_attn_bwd_end(const gatmi_attn *a, int max_chunks, const float *d_a_dst,
+                                  void *node_ws, size_t node_ws_bytes, float *d_att_src,
+                                  float *d_att_dst, float *d_bias, void *stream) {
+    GATMI_REQUIRE(a && d_a_dst && (a->hp || a->shape.num_nodes == 0), "null attn/d_a_dst/hp");
+    Geometry geo;
+    if (int e = make_geometry(a->shape, &geo)) return e;
+    const bool bf = a->feat_bf16 != 0;
+    const size_t need = gatmi_attn_bwd_node_workspace_bytes(&a->shape, max_chunks, bf);
+    if (need == 0 || node_ws_bytes < need) {
+        set_error("attn_bwd node workspace too small: %zu < %zu", node_ws_bytes, need);
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    NodeWs nw = carve_node(&a->shape, geo, max_chunks, bf, node_ws);
+    const int N = a->shape.num_nodes, H = a->shape.heads, C = a->shape.channels;
+    float *colsum = nw.colsum + (size_t)max_chunks * kColsumBlocks * 2 * geo.Dp;
+    ProfScope ps("param_colsum", st);
+    // sum_i d_a_dst[i] h[i] over the OWN rows (a->hp = their table): slab max_chunks, n_src = 0
+    const int blocks = N < kColsumBlocks ? N : kColsumBlocks;
+    if (N > 0) {
+        if (bf)
+            hipLaunchKernelGGL(colsum_stage1_kernel<bf16x4>, dim3(blocks), dim3(256), 0, st, a->hp,
+                               d_a_dst, d_a_dst, a->att_dst, nullptr, 0, N, 0, H, C, geo.Cp, geo.Dp,
+                               colsum);
+        else
+            hipLaunchKernelGGL(colsum_stage1_kernel<float4>, dim3(blocks), dim3(256), 0, st, a->hp,
+                               d_a_dst, d_a_dst, a->att_dst, nullptr, 0, N, 0, H, C, geo.Cp, geo.Dp,
+                               colsum);
+        GATMI_HIP(hipGetLastError());
+    }
+    if (d_att_src || d_att_dst || d_bias) {
+        const int prep_blocks = N < kColsumBlocks ? N : kColsumBlocks;
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((geo.Dp + 15) / 16, 3), dim3(256), 0, st,
+                           nw.colsum, (max_chunks + 1) * kColsumBlocks, nw.gsum_partial, prep_blocks, H,
+                           C, geo.Cp, geo.Dp, d_att_src, d_att_dst, d_bias);
+        GATMI_HIP(hipGetLastError());
+    }
     return GATMI_OK;
 }

@@ -48,19 +48,85 @@ from torch import Tensor, nn
 from . import _lib
 
 
+class TableMap:
+    """Where every node's row sits in a gathered table that arrives in `chunks` pieces.
+
+    Owner o holds the contiguous node range [bounds[o], bounds[o+1]); its rows are cut into
+    `chunks` consecutive sub-ranges of sub[o] rows, and piece k of the table is the concatenation
+    over the owners of their k-th sub-range -- so that piece k is ONE collective (an all-gather of
+    the k-th sub-range of every rank) that can be in flight while piece k-1 is being consumed.
+      padded (uneven False): every owner's sub-range is padded to the same sub = ceil(block / chunks)
+        rows, block = the longest range: plain equal-shard collectives, world * sub rows per piece;
+      exact (uneven True): sub[o] = ceil(len_o / chunks), no padding rows at all; the collectives are
+        per-owner broadcasts / reductions (dist.gather_piece / reduce_piece).
+    chunks == 1, padded, is the rank-major layout of the one-piece exchange modes."""
+
+    def __init__(self, bounds: Tuple[int, ...], chunks: int = 1, uneven: bool = False):
+        self.bounds = tuple(int(b) for b in bounds)
+        self.world = len(self.bounds) - 1
+        self.chunks = int(chunks)
+        self.uneven = bool(uneven)
+        if self.chunks < 1:
+            raise ValueError(f"chunks must be >= 1, got {chunks}")
+        self.lens = [self.bounds[o + 1] - self.bounds[o] for o in range(self.world)]
+        block = max(max(self.lens), 1)
+        k = self.chunks
+        if self.uneven:
+            self.sub = [(l + k - 1) // k for l in self.lens]
+        else:
+            self.sub = [(block + k - 1) // k] * self.world
+        # cnt[s][o]: real rows of owner o in piece s; cap[s][o]: rows it occupies there
+        self.cnt = [[min(max(self.lens[o] - s * self.sub[o], 0), self.sub[o]) for o in range(self.world)]
+                    for s in range(k)]
+        self.cap = self.cnt if self.uneven else [list(self.sub) for _ in range(k)]
+        self.pre = [[sum(self.cap[s][:o]) for o in range(self.world)] for s in range(k)]
+        self.rows = [sum(self.cap[s]) for s in range(k)]
+        self.base = [sum(self.rows[:s]) for s in range(k)]
+        self.total = sum(self.rows)
+        self._lut = {}
+
+    def _tensors(self, device):
+        t = self._lut.get(device)
+        if t is None:
+            i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=device)
+            start = [[self.base[s] + self.pre[s][o] for o in range(self.world)] for s in range(self.chunks)]
+            t = (i64(self.bounds), i64([max(v, 1) for v in self.sub]), i64(start))
+            self._lut[device] = t
+        return t
+
+    def locate(self, ids: Tensor) -> Tuple[Tensor, Tensor]:
+        """global node ids -> (row in the table, piece that holds it)"""
+        b, sub, start = self._tensors(ids.device)
+        owner = torch.searchsorted(b, ids, right=True) - 1
+        t = ids - b[owner]
+        so = sub[owner]
+        piece = torch.div(t, so, rounding_mode="floor")
+        return start[piece, owner] + (t - piece * so), piece
+
+    def to_table(self, ids: Tensor) -> Tensor:
+        return self.locate(ids)[0]
+
+    def own(self, rank: int, s: int) -> Tuple[int, int, int]:
+        """(first table row, first local row, count) of `rank`'s rows in piece s"""
+        return self.base[s] + self.pre[s][rank], s * self.sub[rank], self.cnt[s][rank]
+
+
 @dataclass
 class Partition:
     """Rank r owns the contiguous destination range [bounds[r], bounds[r+1]).  `bounds` None:
     equal blocks of ceil(N / P) nodes.  Given (balanced_bounds): ranges of unequal length that
     hold about the same number of in-edges -- what the per-rank work is proportional to
-    (SURVEY.md 8e).  Either way every collective is the plain equal-shard form: shards are
+    (SURVEY.md 8e).  uneven False: every collective is the plain equal-shard form, shards are
     padded to `block` = the longest range, and the gathered tables are indexed by PADDED ids
     (rank * block + offset inside the rank's range; `to_padded`) -- for equal blocks those are
-    the global ids themselves."""
+    the global ids themselves.  uneven True (make_partition picks it when padding would add more
+    than 25 % rows): tables hold exactly N rows, indexed by global id, and the collectives move
+    every rank's exact range (gather_rows / scatter_rows)."""
     num_nodes: int
     world: int
     rank: int
     bounds: Optional[Tuple[int, ...]] = None
+    uneven: bool = False
 
     def __post_init__(self):
         if self.bounds is not None:
@@ -69,24 +135,36 @@ class Partition:
                     or any(b[i] > b[i + 1] for i in range(self.world))):
                 raise ValueError(f"bounds {b} do not split {self.num_nodes} nodes over {self.world} ranks")
             self.bounds = b
+        self._maps = {}
+
+    @property
+    def all_bounds(self) -> Tuple[int, ...]:
+        """the ranges written out (equal blocks when `bounds` is None)"""
+        if self.bounds is not None:
+            return self.bounds
+        blk = (self.num_nodes + self.world - 1) // self.world
+        return tuple(min(r * blk, self.num_nodes) for r in range(self.world + 1))
+
+    def table(self, chunks: int = 1) -> TableMap:
+        m = self._maps.get(chunks)
+        if m is None:
+            m = self._maps[chunks] = TableMap(self.all_bounds, chunks, self.uneven)
+        return m
 
     @property
     def block(self) -> int:
+        """rows a rank's shard occupies in an equal-shard collective (the longest range)"""
         if self.bounds is None:
             return (self.num_nodes + self.world - 1) // self.world
         return max(max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world)), 1)
 
     @property
     def lo(self) -> int:
-        if self.bounds is None:
-            return min(self.rank * self.block, self.num_nodes)
-        return self.bounds[self.rank]
+        return self.all_bounds[self.rank]
 
     @property
     def hi(self) -> int:
-        if self.bounds is None:
-            return min(self.lo + self.block, self.num_nodes)
-        return self.bounds[self.rank + 1]
+        return self.all_bounds[self.rank + 1]
 
     @property
     def n_local(self) -> int:
@@ -94,24 +172,33 @@ class Partition:
 
     @property
     def padded_nodes(self) -> int:
-        return self.block * self.world
+        """rows of a gathered one-piece table"""
+        return self.num_nodes if self.uneven else self.block * self.world
+
+    @property
+    def padding_ratio(self) -> float:
+        """rows the collectives move per real row (1.0 = nothing wasted)"""
+        return self.padded_nodes / max(self.num_nodes, 1)
 
     @property
     def plo(self) -> int:
-        """first row of this rank's shard in a gathered (padded) table"""
-        return self.rank * self.block
+        """first row of this rank's shard in a gathered one-piece table"""
+        return self.lo if self.uneven else self.rank * self.block
 
     @property
     def phi(self) -> int:
         return self.plo + self.n_local
 
     def to_padded(self, ids: Tensor) -> Tensor:
-        """global node ids -> rows of a gathered table"""
-        if self.bounds is None:
+        """global node ids -> rows of a gathered one-piece table"""
+        if self.bounds is None or self.uneven:
             return ids
         b = torch.tensor(self.bounds, dtype=ids.dtype, device=ids.device)
         owner = torch.searchsorted(b, ids, right=True) - 1
         return owner * self.block + (ids - b[owner])
+
+
+PAD_LIMIT = 1.25     # make_partition: beyond this many table rows per node the exact collectives run
 
 
 def balanced_bounds(edge_index: Tensor, num_nodes: int, world: int) -> Tuple[int, ...]:
@@ -137,11 +224,17 @@ _PARTS: Dict[Tuple, Tuple["weakref.ref", Tuple[int, ...]]] = {}
 
 
 def make_partition(edge_index: Tensor, num_nodes: int, world: int, rank: int,
-                   balance: str = "edges") -> Partition:
+                   balance: str = "edges", padding: str = "auto") -> Partition:
     """The partition every layer of a network (and its caller, who slices x and y) shares:
-    balance = "edges" (balanced_bounds, cached per edge_index object) or "nodes" (equal blocks)."""
+    balance = "edges" (balanced_bounds, cached per edge_index object) or "nodes" (equal blocks).
+    padding = "pad": equal-shard collectives on shards padded to the longest range; "exact": no
+    padding rows, per-owner collectives; "auto": padded unless that moves more than PAD_LIMIT
+    rows per node (a degree-ordered graph: the range holding the low-degree tail is several
+    times N / P long) -- every rank decides from the same bounds."""
+    if padding not in ("auto", "pad", "exact"):
+        raise ValueError(f"padding must be 'auto', 'pad' or 'exact', got {padding!r}")
     if balance == "nodes":
-        return Partition(num_nodes, world, rank)
+        return Partition(num_nodes, world, rank, None, padding == "exact")
     if balance != "edges":
         raise ValueError(f"balance must be 'edges' or 'nodes', got {balance!r}")
     key = (id(edge_index), edge_index._version, num_nodes, world)
@@ -151,7 +244,9 @@ def make_partition(edge_index: Tensor, num_nodes: int, world: int, rank: int,
             del _PARTS[k]
         hit = (weakref.ref(edge_index), balanced_bounds(edge_index, num_nodes, world))
         _PARTS[key] = hit
-    return Partition(num_nodes, world, rank, hit[1])
+    part = Partition(num_nodes, world, rank, hit[1])
+    part.uneven = padding == "exact" or (padding == "auto" and part.block * world > PAD_LIMIT * max(num_nodes, 1))
+    return part
 
 
 def local_edges(edge_index: Tensor, part: Partition) -> Tensor:
@@ -167,6 +262,23 @@ def local_edges(edge_index: Tensor, part: Partition) -> Tensor:
                         torch.cat([dst[keep] - part.lo, loops])])
 
 
+def chunk_edge_lists(edge_index: Tensor, part: Partition, tm: TableMap):
+    """This rank's share of the normalised edge list (as local_edges) split by the piece of the
+    table that holds each edge's source.  -> per piece (edges [2, E_s], sel [E_s]): row 0 = source
+    rows counted from the piece's first row, row 1 = local destination ids, both in the order of
+    the rank's list; sel = positions of these edges in that list (for injected dropout masks)."""
+    src, dst = edge_index[0], edge_index[1]
+    keep = (dst >= part.lo) & (dst < part.hi) & (src != dst)
+    loops = torch.arange(part.n_local, dtype=edge_index.dtype, device=edge_index.device)
+    rows, piece = tm.locate(torch.cat([src[keep], loops + part.lo]))
+    ldst = torch.cat([dst[keep] - part.lo, loops])
+    out = []
+    for k in range(tm.chunks):
+        sel = torch.nonzero(piece == k).view(-1)
+        out.append((torch.stack([rows[sel] - tm.base[k], ldst[sel]]), sel))
+    return out
+
+
 # ------------------------------------------------------------------ collectives
 def _host_staged(t: Tensor, group) -> bool:
     """gloo rehearsals of the GPU path (two ranks sharing one card): stage device tensors through
@@ -176,13 +288,14 @@ def _host_staged(t: Tensor, group) -> bool:
 
 
 def all_gather_rows(shard: Tensor, world: int, group=None) -> Tensor:
+    """equal shards -> [world * rows, ...]"""
     if _host_staged(shard, group):
         return all_gather_rows(shard.cpu(), world, group).to(shard.device)
     out = shard.new_empty((world * shard.size(0),) + tuple(shard.shape[1:]))
-    try:
-        dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
-    except (RuntimeError, NotImplementedError):   # backends without the flat form
+    if dist.get_backend(group) == "gloo":         # gloo: the list form (no flat all-gather on CPU tensors)
         dist.all_gather(list(out.chunk(world, 0)), shard.contiguous(), group=group)
+    else:                                         # RCCL: an error here is an error, not a cue to retry
+        dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
     return out
 
 
@@ -196,6 +309,151 @@ def reduce_scatter_rows(full: Tensor, world: int, rank: int, group=None) -> Tens
         out.copy_(tmp.chunk(world, 0)[rank])
     else:
         dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
+    return out
+
+
+def _global_rank(group, r: int) -> int:
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+class _Pending:
+    """Collectives in flight (async_op works) and what to do once they are done.  wait() makes the
+    CURRENT stream wait for them (RCCL: no host block) and runs the epilogue once."""
+
+    def __init__(self, works=(), after=None):
+        self.works, self.after = [w for w in works if w is not None], after
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.after is not None:
+            after, self.after = self.after, None
+            after()
+
+
+COMM_MS: Dict[str, list] = {}      # bench: name -> [(start event, end event)] of timed collectives
+_COMM_TIMING = False
+
+
+def comm_timing(on: bool) -> None:
+    """bench.py --gpus N: bracket every collective of the layer with events on the current
+    stream (mode "h" pieces: the time the consumer actually WAITED, i.e. what overlap did not hide)."""
+    global _COMM_TIMING
+    _COMM_TIMING = bool(on)
+    COMM_MS.clear()
+
+
+class _Timed:
+    def __init__(self, name: str, ref: Tensor):
+        self.on = _COMM_TIMING and ref.is_cuda
+        self.name = name
+        if self.on:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.t1.record()
+            COMM_MS.setdefault(self.name, []).append((self.t0, self.t1))
+
+
+def comm_ms_read() -> Dict[str, float]:
+    """-> {name: total milliseconds since comm_timing(True)} (synchronises)"""
+    torch.cuda.synchronize()
+    out = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in COMM_MS.items()}
+    COMM_MS.clear()
+    return out
+
+
+def gather_piece(local: Tensor, tm: TableMap, s: int, rank: int, out: Tensor, group=None,
+                 async_op: bool = False) -> _Pending:
+    """Piece s of the table: every rank's s-th sub-range -> out [tm.rows[s], ...] (a view of the
+    table).  `local` holds this rank's rows from row 0; padded maps need tm.chunks * tm.sub[rank]
+    rows of it (zero rows behind the real ones).  Padded: one equal-shard all-gather; exact: one
+    broadcast per owner of its exact rows."""
+    _, l0, cnt = tm.own(rank, s)
+    if tm.rows[s] == 0:
+        return _Pending()
+    if _host_staged(local, group):                 # gloo rehearsal on a shared card: through the host
+        host = local.new_empty((tm.rows[s],) + tuple(local.shape[1:]), device="cpu")
+        gather_piece(local.cpu(), tm, s, rank, host, group).wait()
+        out.copy_(host)
+        return _Pending()
+    if not tm.uneven:
+        sub = tm.sub[rank]
+        src = local[l0:l0 + sub]
+        if src.size(0) != sub:
+            raise ValueError(f"padded piece {s} needs rows [{l0}, {l0 + sub}) of the local shard, "
+                             f"which has {local.size(0)}")
+        if dist.get_backend(group) == "gloo":
+            w = dist.all_gather(list(out.chunk(tm.world, 0)), src.contiguous(), group=group, async_op=async_op)
+        else:
+            w = dist.all_gather_into_tensor(out, src.contiguous(), group=group, async_op=async_op)
+        return _Pending([w])
+    works = []
+    for o in range(tm.world):
+        c = tm.cnt[s][o]
+        if c == 0:
+            continue
+        view = out[tm.pre[s][o]: tm.pre[s][o] + c]
+        if o == rank:
+            view.copy_(local[l0:l0 + c])
+        works.append(dist.broadcast(view, src=_global_rank(group, o), group=group, async_op=async_op))
+    return _Pending(works)
+
+
+def reduce_piece(full: Tensor, tm: TableMap, s: int, rank: int, out: Tensor, group=None,
+                 async_op: bool = False) -> _Pending:
+    """The adjoint: piece s of a table of partial sums [tm.rows[s], ...] -> this rank's rows of
+    it, summed over the ranks, into out [tm.sub[rank] (padded) or tm.cnt[s][rank] (exact), ...]."""
+    if tm.rows[s] == 0:
+        return _Pending()
+    if _host_staged(full, group):
+        host = out.new_empty(out.shape, device="cpu")
+        reduce_piece(full.cpu(), tm, s, rank, host, group).wait()
+        out.copy_(host)
+        return _Pending()
+    gloo = dist.get_backend(group) == "gloo"
+    if not tm.uneven and not gloo:
+        return _Pending([dist.reduce_scatter_tensor(out, full, group=group, async_op=async_op)])
+    if not tm.uneven:                             # gloo has no reduce-scatter: reduce, then slice
+        tmp = full.clone()
+        w = dist.all_reduce(tmp, group=group, async_op=async_op)
+        lo = tm.pre[s][rank]
+        return _Pending([w], lambda: out.copy_(tmp[lo:lo + out.size(0)]))
+    works, mine = [], None
+    for o in range(tm.world):
+        c = tm.cnt[s][o]
+        if c == 0:
+            continue
+        view = full[tm.pre[s][o]: tm.pre[s][o] + c]
+        works.append(dist.reduce(view, dst=_global_rank(group, o), group=group, async_op=async_op))
+        if o == rank:
+            mine = view
+    return _Pending(works, (lambda: out.copy_(mine)) if mine is not None else None)
+
+
+def gather_rows(local: Tensor, part: Partition, group=None) -> Tensor:
+    """every rank's rows -> the one-piece table [part.padded_nodes, ...]"""
+    if not part.uneven:
+        return all_gather_rows(_pad_rows(local, part.block), part.world, group)
+    out = local.new_empty((part.num_nodes,) + tuple(local.shape[1:]))
+    gather_piece(local, part.table(1), 0, part.rank, out, group).wait()
+    return out
+
+
+def scatter_rows(full: Tensor, part: Partition, group=None) -> Tensor:
+    """reduce-scatter of a one-piece table of partial sums -> this rank's rows [n_local, ...]"""
+    if not part.uneven:
+        return reduce_scatter_rows(full, part.world, part.rank, group)[:part.n_local]
+    out = full.new_empty((part.n_local,) + tuple(full.shape[1:]))
+    reduce_piece(full.contiguous(), part.table(1), 0, part.rank, out, group).wait()
     return out
 
 
@@ -243,6 +501,30 @@ class HipBackend:
     def bf16_supported(self, f, cfg):
         from . import ops
         return ops.project_bf16_supported(f, cfg.heads, cfg.channels)
+
+    # source chunks (exchange "h" pipelined: PartitionedGATConv(chunks=K))
+    def project_fwd_padded(self, x, w, att_d, cfg, rows):
+        """project_fwd into a table of `rows` >= len(x) rows (zero rows behind the real ones), so the
+        equal-shard pieces of a padded map are views of it"""
+        from . import ops
+        fwd = ops.project_fwd_bf16 if cfg.feat_bf16 else ops.project_fwd
+        return fwd(x, w, att_d, cfg.heads, cfg.channels, alloc_rows=rows)
+
+    def build_chunk_layout(self, edges: Tensor, num_src: int, num_dst: int):
+        from .graph import build_graph
+        return build_graph(edges, num_src, add_self_loops=False, seg_len=self.seg_len, num_dst=num_dst)
+
+    def attn_fwd_partial(self, layout, cfg, f, hp_piece, a_dst, att_s):
+        from . import ops
+        return ops.attn_fwd_partial(layout, cfg, f, hp_piece, a_dst, att_s)
+
+    def attn_fwd_combine(self, parts, cfg, bias, need_lse):
+        from . import ops
+        return ops.attn_fwd_combine(parts, cfg, bias, need_lse)
+
+    def chunked_backward(self, cfg, f, a_dst, att_s, att_d, bias, out, lse, grad_out, max_chunks):
+        from . import ops
+        return ops.ChunkedBackward(cfg, f, a_dst, att_s, att_d, bias, out, lse, grad_out, max_chunks)
 
     def attn_fwd(self, layout, cfg, f, hp_full, a_dst, att_s, att_d, bias, need_lse):
         from . import ops
@@ -317,13 +599,13 @@ class _PartitionedFn(torch.autograd.Function):
         bias_c = None if bias is None else bias.contiguous()
         f = x_local.size(1)
         if exchange == "x":
-            x_full = all_gather_rows(_pad_rows(x_local, part.block), part.world, group)
+            x_full = gather_rows(x_local, part, group)
             hp_full, a_dst_full = be.project_fwd(x_full, weight, att_d, cfg)
             a_dst = a_dst_full[part.plo:part.phi].contiguous()
             x_saved = x_full
         else:
             hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
-            hp_full = all_gather_rows(_pad_rows(hp_local, part.block), part.world, group)
+            hp_full = gather_rows(hp_local, part, group)
             x_saved = x_local
         need_grad = any(ctx.needs_input_grad[:5])
         out, lse = be.attn_fwd(layout, cfg, f, hp_full, a_dst, att_s, att_d, bias_c, need_grad)
@@ -346,13 +628,116 @@ class _PartitionedFn(torch.autograd.Function):
             d_w, d_x_part = be.project_bwd(x_saved, weight, d_hp_part, cfg, need_dx)
             d_x = None
             if need_dx:
-                d_x = reduce_scatter_rows(d_x_part, part.world, part.rank, group)[:part.n_local]
+                d_x = scatter_rows(d_x_part, part, group)
         else:
-            d_hp = reduce_scatter_rows(d_hp_part, part.world, part.rank, group)[:part.n_local]
+            d_hp = scatter_rows(d_hp_part, part, group)
             d_hp = d_hp.contiguous()
             be.add_dst_term(d_hp, d_a_dst, att_d, cfg)
             d_w, d_x = be.project_bwd(x_saved, weight, d_hp, cfg, need_dx)
         all_reduce_many([d_w, d_as, d_ad, d_b], group)
+        return (d_x, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
+                None, None, None, None, None, None)
+
+
+_SEED_STEP = 0x9E3779B97F4A7C15      # per-piece dropout streams: seed + k * this (mod 2^63)
+
+
+def _piece_cfg(cfg, k: int):
+    """The attention config of piece k: a hash-dropout stream of its own (the pieces' layouts count
+    their edges from 0 each, so one seed would repeat the keep pattern piece after piece), or the
+    piece's slice of an injected byte mask (tests: cfg.piece_masks)."""
+    import copy
+    c = copy.copy(cfg)
+    if cfg.mask_mode in (_lib.MASK_HASH,):
+        c.seed = (int(cfg.seed) + k * _SEED_STEP) % (1 << 63)
+    masks = getattr(cfg, "piece_masks", None)
+    if masks is not None:
+        c.mask = masks[k]
+    return c
+
+
+class _PipelinedFn(torch.autograd.Function):
+    """exchange == "h" in `tm.chunks` pieces, compute overlapped with the collectives (SURVEY.md 8e
+    "Overlap"): the all-gather of the projected rows is issued as one asynchronous collective per
+    piece (every rank's k-th sub-range), the fused attention runs over the sources of piece k --
+    a rectangular layout of its own -- as soon as it has arrived and while piece k+1 is in flight,
+    and the per-piece (m, s, acc) triples are joined at the end.  Backward: the edge pass over
+    piece k's transposed CSR yields the complete d_h of that piece's rows; its reduce-scatter
+    starts while piece k+1 computes."""
+
+    @staticmethod
+    def forward(ctx, x_local, weight, att_src, att_dst, bias, part, tm, layouts, cfg, be, group):
+        x_local, weight = x_local.contiguous(), weight.contiguous()
+        att_s, att_d = att_src.contiguous().view(-1), att_dst.contiguous().view(-1)
+        bias_c = None if bias is None else bias.contiguous()
+        f, k, rank, n_loc = x_local.size(1), tm.chunks, part.rank, part.n_local
+        rows_alloc = n_loc if tm.uneven else k * tm.sub[rank]
+        padded = getattr(be, "project_fwd_padded", None)
+        if padded is not None:
+            hp_local, a_dst = padded(x_local, weight, att_d, cfg, rows_alloc)
+        else:
+            hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
+            hp_local = _pad_rows(hp_local, rows_alloc)
+        table = hp_local.new_empty((tm.total, hp_local.size(1)))
+        piece = lambda t, s: t[tm.base[s]: tm.base[s] + tm.rows[s]]
+        pend = [gather_piece(hp_local, tm, s, rank, piece(table, s), group, async_op=True)
+                for s in range(k)]
+        need_grad = any(ctx.needs_input_grad[:5])
+        parts = []
+        for s in range(k):
+            with _Timed("wait_gather_h", table):
+                pend[s].wait()
+            if tm.rows[s] and n_loc:
+                parts.append(be.attn_fwd_partial(layouts[s], _piece_cfg(cfg, s), f, piece(table, s),
+                                                 a_dst, att_s))
+        if parts:
+            out, lse = be.attn_fwd_combine(parts, cfg, bias_c, need_grad)
+        else:
+            out = x_local.new_zeros((0, weight.size(0)))
+            lse = x_local.new_zeros((0, cfg.heads))
+        if need_grad:
+            ctx.save_for_backward(x_local, weight, att_s, att_d, bias_c, table, hp_local, a_dst, out, lse)
+            ctx.misc = (part, tm, layouts, cfg, be, group, att_src.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_local, weight, att_s, att_d, bias_c, table, hp_local, a_dst, out, lse = ctx.saved_tensors
+        part, tm, layouts, cfg, be, group, att_shape = ctx.misc
+        need_dx = ctx.needs_input_grad[0]
+        f, k, rank, n_loc = x_local.size(1), tm.chunks, part.rank, part.n_local
+        dp = table.size(1)
+        piece = lambda t, s: t[tm.base[s]: tm.base[s] + tm.rows[s]]
+        cb = None
+        if n_loc:
+            cb = be.chunked_backward(cfg, f, a_dst, att_s, att_d, bias_c, out, lse,
+                                     grad_out.contiguous(), k)
+        d_own = x_local.new_zeros((n_loc if tm.uneven else k * tm.sub[rank], dp))
+        pend = []
+        for s in range(k):
+            if tm.rows[s] == 0:
+                continue
+            if cb is not None:
+                d_piece = cb.chunk(s, layouts[s], _piece_cfg(cfg, s), piece(table, s))
+            else:                                  # a rank without rows still takes part in the sums
+                d_piece = x_local.new_zeros((tm.rows[s], dp))
+            _, l0, cnt = tm.own(rank, s)
+            pend.append(reduce_piece(d_piece, tm, s, rank, d_own[l0: l0 + (cnt if tm.uneven else tm.sub[rank])],
+                                     group, async_op=True))
+        if cb is not None:
+            d_as, d_ad, d_b, d_a_dst = cb.end(hp_local[:n_loc])
+        else:
+            d_as, d_ad = torch.zeros_like(att_s), torch.zeros_like(att_d)
+            d_b = None if bias_c is None else torch.zeros_like(bias_c)
+            d_a_dst = x_local.new_zeros((0, cfg.heads))
+        with _Timed("wait_scatter_dh", table):
+            for p in pend:
+                p.wait()
+        d_hp = d_own[:n_loc]
+        be.add_dst_term(d_hp, d_a_dst, att_d, cfg)
+        d_w, d_x = be.project_bwd(x_local, weight, d_hp, cfg, need_dx)
+        with _Timed("allreduce_params", table):
+            all_reduce_many([d_w, d_as, d_ad, d_b], group)
         return (d_x, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
                 None, None, None, None, None, None)
 
@@ -371,7 +756,7 @@ class _PartitionedInAggFn(torch.autograd.Function):
         bias_c = None if bias is None else bias.contiguous()
         xs_local, a_dst = be.inagg_pack(x_local, weight, att_s, att_d, cfg)
         if exchange == "xs":
-            table = all_gather_rows(_pad_rows(xs_local, part.block), part.world, group)
+            table = gather_rows(xs_local, part, group)
         else:
             c0, cn = be.inagg_logit_columns(x_local.size(1), cfg)
             # The cached table is valid for THIS x tensor object at THIS version only: a pointer
@@ -381,14 +766,14 @@ class _PartitionedInAggFn(torch.autograd.Function):
             # all-gather every step -- the same traffic as exchange="xs".
             owner = cache.get("owner")
             hit = (owner is not None and owner() is x_local and cache.get("version") == x_local._version
-                   and cache.get("world") == part.world and cache.get("bounds") == part.bounds)
+                   and cache.get("world") == part.world
+                   and cache.get("bounds") == (part.bounds, part.uneven))
             if not hit:                       # first call for this x: replicate the rows once
-                cache["table"] = all_gather_rows(_pad_rows(xs_local, part.block), part.world, group)
+                cache["table"] = gather_rows(xs_local, part, group)
                 cache["owner"], cache["version"] = weakref.ref(x_local), x_local._version
-                cache["world"], cache["bounds"] = part.world, part.bounds
+                cache["world"], cache["bounds"] = part.world, (part.bounds, part.uneven)
             else:                             # later calls: only the logits travel
-                logits = all_gather_rows(_pad_rows(xs_local[:, c0:c0 + cn], part.block),
-                                         part.world, group)
+                logits = gather_rows(xs_local[:, c0:c0 + cn].contiguous(), part, group)
                 cache["table"][:, c0:c0 + cn] = logits
             table = cache["table"]
         # bf16 copy of the table for the edge kernels' gathers (cfg.rows16).  Exchange "as": its x
@@ -433,12 +818,22 @@ class PartitionedGATConv(nn.Module):
 
     def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, dropout=0.0,
                  bias=True, backend=None, group=None, exchange="auto", balance="edges",
-                 feature_dtype=None):
+                 feature_dtype=None, chunks=None, padding="auto"):
         super().__init__()
         from .layer import _glorot_
         if balance not in ("edges", "nodes"):
             raise ValueError(f"balance must be 'edges' or 'nodes', got {balance!r}")
         self.balance = balance      # destination ranges of equal in-edge count / equal node count
+        self.padding = padding      # make_partition: "auto" | "pad" | "exact"
+        # exchange "h" in `chunks` pieces with the attention of piece k overlapping the collective of
+        # piece k+1 (_PipelinedFn).  None: GAT_PIPELINE_CHUNKS, else 4 when there is anyone to talk to
+        # (the first piece's transfer and the last piece's kernels are what stays exposed: ~1/4 each)
+        if chunks is None:
+            env = os.environ.get("GAT_PIPELINE_CHUNKS")
+            chunks = int(env) if env else 0
+        if not 0 <= int(chunks) <= _lib.MAX_PARTS:
+            raise ValueError(f"chunks must be in [0, {_lib.MAX_PARTS}] (0: pick), got {chunks}")
+        self.chunks = int(chunks)
         # torch.bfloat16: exchange "h" projects into a bf16 table, all-gathers THAT (half the xGMI
         # volume) and gathers bf16 rows; d_h travels back in f32.  Exchange "xs" / "as":
         # the edge kernels gather a bf16 copy of the packed table (what travels stays f32).  "x": f32.
@@ -458,22 +853,41 @@ class PartitionedGATConv(nn.Module):
             raise ValueError(f"unknown exchange mode {exchange!r}")
         self.exchange = exchange
         self._layouts = None
+        self._piece_layouts = None
         self._table_cache = {}
 
     def partition_for(self, edge_index: Tensor, num_nodes: int) -> Partition:
         """This rank's destination range for the graph (the caller slices x, y, grad_out by it)."""
         return make_partition(edge_index, num_nodes, dist.get_world_size(self.group),
-                              dist.get_rank(self.group), self.balance)
+                              dist.get_rank(self.group), self.balance, self.padding)
+
+    def pieces(self, part: Partition) -> int:
+        """how many pieces exchange "h" travels in"""
+        if self.chunks:
+            return self.chunks
+        return 4 if part.world > 1 else 1
+
+    def piece_layouts_for(self, edge_index: Tensor, part: Partition, tm: TableMap):
+        """One rectangular layout per piece of the table (the edges whose sources the piece holds),
+        built once per edge_index object like layout_for's."""
+        owner, version, key, layouts = self._piece_layouts or (None, None, None, None)
+        want = (part.rank, part.world, part.bounds, part.uneven, tm.chunks)
+        if owner is None or owner() is not edge_index or version != edge_index._version or key != want:
+            layouts = [self.backend.build_chunk_layout(edges, tm.rows[k], part.n_local)
+                       if tm.rows[k] and part.n_local else None
+                       for k, (edges, _) in enumerate(chunk_edge_lists(edge_index, part, tm))]
+            self._piece_layouts = (weakref.ref(edge_index), edge_index._version, want, layouts)
+        return layouts
 
     def layout_for(self, edge_index: Tensor, part: Partition):
         """The rank's CSR, built once per edge_index OBJECT (weak reference + version: an address
         reused by another tensor of the same shape does not match)."""
         owner, version, key, layout = self._layouts or (None, None, None, None)
         if (owner is None or owner() is not edge_index or version != edge_index._version
-                or key != (part.rank, part.world, part.bounds)):
+                or key != (part.rank, part.world, part.bounds, part.uneven)):
             layout = self.backend.build_layout(local_edges(edge_index, part), part)
             self._layouts = (weakref.ref(edge_index), edge_index._version,
-                             (part.rank, part.world, part.bounds), layout)
+                             (part.rank, part.world, part.bounds, part.uneven), layout)
         return layout
 
     def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
@@ -482,7 +896,6 @@ class PartitionedGATConv(nn.Module):
         if x_local.size(0) != part.n_local:
             raise ValueError(f"rank {part.rank} owns nodes [{part.lo}, {part.hi}) but got "
                              f"{x_local.size(0)} rows of x")
-        layout = self.layout_for(edge_index, part)
         mask_mode, seed = _lib.MASK_NONE, 0
         if self.training and self.dropout > 0.0:
             mask_mode = _lib.MASK_HASH
@@ -490,6 +903,8 @@ class PartitionedGATConv(nn.Module):
         cfg = AttnConfig(self.heads, self.out_channels, self.negative_slope, self.dropout,
                          mask_mode, seed, None)
         mode = self.resolve_exchange(x_local, cfg)
+        pipelined = mode == "h" and self.pieces(part) > 1
+        layout = None if pipelined else self.layout_for(edge_index, part)
         cfg.feat_bf16 = (mode == "h" and self.feature_dtype == torch.bfloat16
                          and getattr(self.backend, "bf16_supported", lambda f, c: False)(self.in_channels, cfg))
         cfg.rows16 = bool(mode in ("xs", "as") and self.feature_dtype == torch.bfloat16 and
@@ -498,6 +913,11 @@ class PartitionedGATConv(nn.Module):
             return _PartitionedInAggFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
                                              self.bias, part, layout, cfg, self.backend,
                                              self.group, mode, self._table_cache)
+        if pipelined:
+            tm = part.table(self.pieces(part))
+            return _PipelinedFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst, self.bias,
+                                      part, tm, self.piece_layouts_for(edge_index, part, tm), cfg,
+                                      self.backend, self.group)
         return _PartitionedFn.apply(x_local, self.lin.weight, self.att_src, self.att_dst,
                                     self.bias, part, layout, cfg, self.backend, self.group, mode)
 

@@ -53,14 +53,25 @@ class AttnConfig:
         return a
 
 
-def project_fwd(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int
-                ) -> Tuple[Tensor, Tensor]:
-    """h = lin(x) in the head-padded layout [N, H*Cp] and a_dst [N, H]."""
+def _alloc_table(n: int, cols: int, dtype, dev, alloc_rows: Optional[int]) -> Tensor:
+    """[max(n, alloc_rows), cols]; the rows behind the first n (a shard padded for an equal-shard
+    collective) are zero"""
+    rows = n if alloc_rows is None else max(int(alloc_rows), n)
+    t = torch.empty(rows, cols, dtype=dtype, device=dev)
+    if rows > n:
+        t[n:].zero_()
+    return t
+
+
+def project_fwd(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int,
+                alloc_rows: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """h = lin(x) in the head-padded layout [N, H*Cp] and a_dst [N, H].  alloc_rows: the table is
+    allocated with that many rows (>= N; the extra rows are zero)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
     shape = _lib.Shape(n, f, heads, channels)
     with torch.cuda.device(dev):
-        hp = torch.empty(n, heads * padded_channels(channels), dtype=torch.float32, device=dev)
+        hp = _alloc_table(n, heads * padded_channels(channels), torch.float32, dev, alloc_rows)
         a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
         ws = _ws(lib.gatmi_project_workspace_bytes(C.byref(shape)), dev)
         _lib.check(lib.gatmi_project_fwd(C.byref(shape), x.data_ptr(), weight.data_ptr(),
@@ -94,14 +105,14 @@ def project_bf16_supported(in_features: int, heads: int, channels: int) -> bool:
     return bool(_lib.lib().gatmi_project_bf16_supported(C.byref(shape)))
 
 
-def project_fwd_bf16(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int
-                     ) -> Tuple[Tensor, Tensor]:
+def project_fwd_bf16(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int,
+                     alloc_rows: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     """bf16 MFMA projection: the bfloat16 feature table [N, H*Cp] and a_dst [N, H] (f32)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
     shape = _lib.Shape(n, f, heads, channels)
     with torch.cuda.device(dev):
-        hp16 = torch.empty(n, heads * padded_channels(channels), dtype=torch.bfloat16, device=dev)
+        hp16 = _alloc_table(n, heads * padded_channels(channels), torch.bfloat16, dev, alloc_rows)
         a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
         ws = _ws(lib.gatmi_project_bf16_workspace_bytes(C.byref(shape)), dev)
         _lib.check(lib.gatmi_project_fwd_bf16(C.byref(shape), x.data_ptr(), weight.data_ptr(),
@@ -165,6 +176,126 @@ def attn_bwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor,
                                       d_ad.data_ptr(), _ptr(d_b), _ptr(d_a_dst), ws.data_ptr(),
                                       ws.numel(), _stream(dev)), "gatmi_attn_bwd")
     return d_hp, d_as, d_ad, d_b, d_a_dst
+
+
+# ------------------------------------------------------------------ source chunks (pipelined exchange)
+def attn_fwd_partial(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp_chunk: Tensor,
+                     a_dst: Tensor, att_src: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """One source chunk of the forward: hp_chunk [layout.num_nodes, Dp] is the chunk's slice of the
+    feature table, `layout` the chunk's own rectangular layout.  -> the un-normalised triple
+    (m [num_dst, H], s [num_dst, H], acc [num_dst, Dp]) of every destination row."""
+    lib, dev = _lib.lib(), a_dst.device
+    n = layout.num_dst
+    if hp_chunk.size(0) != layout.num_nodes:
+        raise ValueError(f"chunk table has {hp_chunk.size(0)} rows, its layout {layout.num_nodes} sources")
+    with torch.cuda.device(dev):
+        a = cfg.c_args(n, in_features, hp_chunk, a_dst, att_src, None, None)
+        dp = cfg.heads * padded_channels(cfg.channels)
+        m = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev)
+        s = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev)
+        acc = torch.empty(n, dp, dtype=torch.float32, device=dev)
+        part = _lib.AttnPartial(m.data_ptr(), s.data_ptr(), acc.data_ptr())
+        ws = _ws(lib.gatmi_attn_fwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
+        _lib.check(lib.gatmi_attn_fwd_partial(layout.ref, C.byref(a), C.byref(part), ws.data_ptr(),
+                                              ws.numel(), _stream(dev)), "gatmi_attn_fwd_partial")
+    return m, s, acc
+
+
+def attn_fwd_combine(parts, cfg: AttnConfig, bias: Optional[Tensor], need_lse: bool
+                     ) -> Tuple[Tensor, Optional[Tensor]]:
+    """The triples of all chunks (in this order) -> out [num_dst, H*C], lse [num_dst, H]."""
+    lib = _lib.lib()
+    if not 1 <= len(parts) <= _lib.MAX_PARTS:
+        raise ValueError(f"{len(parts)} chunks: between 1 and {_lib.MAX_PARTS}")
+    dev, n = parts[0][0].device, parts[0][0].size(0)
+    with torch.cuda.device(dev):
+        arr = (_lib.AttnPartial * len(parts))(*[
+            _lib.AttnPartial(m.data_ptr(), s.data_ptr(), acc.data_ptr()) for m, s, acc in parts])
+        shape = _lib.Shape(n, 1, cfg.heads, cfg.channels)
+        out = torch.empty(n, cfg.heads * cfg.channels, dtype=torch.float32, device=dev)
+        lse = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev) if need_lse else None
+        _lib.check(lib.gatmi_attn_fwd_combine(C.byref(shape), len(parts), arr, _ptr(bias),
+                                              out.data_ptr(), _ptr(lse), _stream(dev)),
+                   "gatmi_attn_fwd_combine")
+    return out, lse
+
+
+class ChunkedBackward:
+    """gatmi_attn_bwd_begin / _chunk / _end: the backward of the fused attention over source chunks.
+    begin() prepares the destination rows once; chunk(k, ...) returns the complete d_h of chunk k's
+    source rows (ready for its reduce-scatter) and accumulates d_a_dst; end() the parameter sums."""
+
+    def __init__(self, cfg: AttnConfig, in_features: int, a_dst: Tensor, att_src: Tensor,
+                 att_dst: Tensor, bias: Optional[Tensor], out: Tensor, lse: Tensor, grad_out: Tensor,
+                 max_chunks: int):
+        self.lib, self.dev = _lib.lib(), a_dst.device
+        self.cfg, self.f, self.k = cfg, in_features, int(max_chunks)
+        self.a_dst, self.att_src, self.att_dst, self.bias = a_dst, att_src, att_dst, bias
+        self.grad_out = grad_out
+        self.n = a_dst.size(0)
+        self.first = True
+        with torch.cuda.device(self.dev):
+            shape = _lib.Shape(self.n, in_features, cfg.heads, cfg.channels)
+            nbytes = self.lib.gatmi_attn_bwd_node_workspace_bytes(C.byref(shape), self.k, int(bool(cfg.feat_bf16)))
+            if nbytes == 0:
+                raise RuntimeError(f"chunked backward: {max_chunks} chunks (at most {_lib.MAX_PARTS}) "
+                                   f"or layer {cfg.heads} x {cfg.channels} not covered")
+            self.node_ws = _ws(nbytes, self.dev)
+            self.d_a_dst = torch.empty(self.n, cfg.heads, dtype=torch.float32, device=self.dev)
+            a = self._args(None)
+            _lib.check(self.lib.gatmi_attn_bwd_begin(C.byref(a), self.k, out.data_ptr(), lse.data_ptr(),
+                                                     grad_out.data_ptr(), self.node_ws.data_ptr(),
+                                                     self.node_ws.numel(), _stream(self.dev)),
+                       "gatmi_attn_bwd_begin")
+
+    def _args(self, hp, cfg=None):
+        cfg = cfg or self.cfg
+        a = _lib.Attn()
+        a.shape = _lib.Shape(self.n, self.f, cfg.heads, cfg.channels)
+        a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
+        a.mask_mode, a.seed, a.mask = cfg.mask_mode, cfg.seed, _ptr(cfg.mask)
+        a.feat_bf16 = int(bool(cfg.feat_bf16))
+        if hp is not None and (hp.dtype == torch.bfloat16) != bool(cfg.feat_bf16):
+            raise TypeError(f"feature table is {hp.dtype} but feat_bf16={cfg.feat_bf16}")
+        a.hp, a.a_dst = _ptr(hp), _ptr(self.a_dst)
+        a.att_src, a.att_dst, a.bias = _ptr(self.att_src), _ptr(self.att_dst), _ptr(self.bias)
+        return a
+
+    def chunk(self, k: int, layout: GraphLayout, cfg_k: AttnConfig, hp_chunk: Tensor,
+              d_hp_out: Optional[Tensor] = None) -> Tensor:
+        """-> d_hp of the chunk's source rows [layout.num_nodes, Dp] (f32), into d_hp_out if given."""
+        if hp_chunk.size(0) != layout.num_nodes or layout.num_dst != self.n:
+            raise ValueError("chunk table / layout do not match")
+        with torch.cuda.device(self.dev):
+            dp = cfg_k.heads * padded_channels(cfg_k.channels)
+            d_hp = d_hp_out if d_hp_out is not None else torch.empty(
+                layout.num_nodes, dp, dtype=torch.float32, device=self.dev)
+            if (d_hp.shape != (layout.num_nodes, dp) or d_hp.dtype != torch.float32
+                    or not d_hp.is_contiguous()):
+                raise ValueError("d_hp_out must be a contiguous float32 [chunk rows, Dp] tensor")
+            a = self._args(hp_chunk, cfg_k)
+            ws = _ws(self.lib.gatmi_attn_bwd_chunk_workspace_bytes(layout.ref, C.byref(a.shape)), self.dev)
+            _lib.check(self.lib.gatmi_attn_bwd_chunk(
+                layout.ref, C.byref(a), int(k), self.k, int(not self.first), self.grad_out.data_ptr(),
+                self.node_ws.data_ptr(), self.node_ws.numel(), d_hp.data_ptr(), self.d_a_dst.data_ptr(),
+                ws.data_ptr(), ws.numel(), _stream(self.dev)), "gatmi_attn_bwd_chunk")
+            self.first = False
+        return d_hp
+
+    def end(self, hp_own: Tensor):
+        """hp_own: the table rows of the destination rows themselves.  -> d_att_src, d_att_dst, d_bias, d_a_dst"""
+        with torch.cuda.device(self.dev):
+            if self.first:                        # no chunk ran (no edges at all)
+                self.d_a_dst.zero_()
+            a = self._args(hp_own)
+            d_as = torch.empty_like(self.att_src)
+            d_ad = torch.empty_like(self.att_dst)
+            d_b = torch.empty_like(self.bias) if self.bias is not None else None
+            _lib.check(self.lib.gatmi_attn_bwd_end(C.byref(a), self.k, self.d_a_dst.data_ptr(),
+                                                   self.node_ws.data_ptr(), self.node_ws.numel(),
+                                                   d_as.data_ptr(), d_ad.data_ptr(), _ptr(d_b),
+                                                   _stream(self.dev)), "gatmi_attn_bwd_end")
+        return d_as, d_ad, d_b, self.d_a_dst
 
 
 def attn_bf16_supported(heads: int, channels: int) -> bool:

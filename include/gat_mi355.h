@@ -211,6 +211,54 @@ int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const float *out,
                    float *d_att_src, float *d_att_dst, float *d_bias, float *d_a_dst_out,
                    void *ws, size_t ws_bytes, void *stream);
 
+/* ---- Source chunks: the same layer call (model.py:40,43,46; backward model.py:54) when the
+ * feature table arrives in pieces -- the pipelined all-gather of a destination partition
+ * ("chunk the all-gather by source range and start aggregating rows whose sources have
+ * arrived"; no counterpart in the single-process reference).  Chunk k owns a slice of the table and
+ * a rectangular layout of its own: the edges whose sources lie in the slice, source ids counted
+ * from the slice's first row (num_src = rows of the slice), all num_dst destination rows
+ * (gatmi_graph_build with add_self_loops = 0; a destination's loop goes into the chunk that holds
+ * its own row).  a->hp points at the slice.  Nothing allocates; the kernels are those of
+ * gatmi_attn_fwd / gatmi_attn_bwd.
+ *
+ * Forward: gatmi_attn_fwd_partial per chunk (as soon as its slice has arrived) leaves the
+ * un-normalised online-softmax triple of every destination row over the chunk's edges,
+ *     m [num_dst, H] running maximum (-inf: no edge),  s [num_dst, H] = sum exp(z - m),
+ *     acc [num_dst, Dp] = sum keep/(1-p) exp(z - m) h[j];
+ * gatmi_attn_fwd_combine joins the triples of all chunks, in the order given (results are bitwise
+ * reproducible for a fixed chunking), into out and lse exactly as gatmi_attn_fwd joins the
+ * segments of a cut row.  Workspace of the partial call: gatmi_attn_fwd_workspace_bytes(g, s). */
+#define GATMI_MAX_PARTS 16
+typedef struct gatmi_attn_partial {
+    float *m, *s, *acc;
+} gatmi_attn_partial;
+int gatmi_attn_fwd_partial(const gatmi_graph *g, const gatmi_attn *a, const gatmi_attn_partial *p,
+                           void *ws, size_t ws_bytes, void *stream);
+int gatmi_attn_fwd_combine(const gatmi_shape *s /* num_nodes = destination rows */, int n_parts,
+                           const gatmi_attn_partial *parts /* host array [n_parts] */,
+                           const float *bias, float *out, float *lse, void *stream);
+
+/* Backward over source chunks.  gatmi_attn_bwd_begin once (per-node preparation into `node_ws`,
+ * which the later calls read: gatmi_attn_bwd_node_workspace_bytes; a->a_dst, a->bias, shape and
+ * feat_bf16 are used, a->hp is not).  gatmi_attn_bwd_chunk per chunk, in any order, on the same
+ * stream: d_hp [g->num_src, Dp] receives the COMPLETE gradient of the chunk's source rows from
+ * this rank's edges (ready for that chunk's reduce-scatter while the next chunk computes; the
+ * d_a_dst * att_dst term of destination rows is not in it, as with gatmi_attn_bwd's
+ * d_a_dst_out); d_a_dst [num_dst, H] is written when accumulate == 0 and added to otherwise;
+ * `chunk` < max_chunks names the chunk's slot for the d_att_src partial sums.
+ * gatmi_attn_bwd_end: a->hp = the table of the destination rows themselves [num_dst, Dp];
+ * -> d_att_src, d_att_dst, d_bias [H*C] (this rank's partial sums; NULL to skip). */
+size_t gatmi_attn_bwd_node_workspace_bytes(const gatmi_shape *s, int max_chunks, int feat_bf16);
+size_t gatmi_attn_bwd_chunk_workspace_bytes(const gatmi_graph *g, const gatmi_shape *s);
+int gatmi_attn_bwd_begin(const gatmi_attn *a, int max_chunks, const float *out, const float *lse,
+                         const float *grad_out, void *node_ws, size_t node_ws_bytes, void *stream);
+int gatmi_attn_bwd_chunk(const gatmi_graph *g, const gatmi_attn *a, int chunk, int max_chunks,
+                         int accumulate, const float *grad_out, void *node_ws, size_t node_ws_bytes,
+                         float *d_hp, float *d_a_dst, void *ws, size_t ws_bytes, void *stream);
+int gatmi_attn_bwd_end(const gatmi_attn *a, int max_chunks, const float *d_a_dst, void *node_ws,
+                       size_t node_ws_bytes, float *d_att_src, float *d_att_dst, float *d_bias,
+                       void *stream);
+
 /* ---- bf16 feature tables (BASELINE.json north_star: "bf16 stated separately").  The edge
  * kernels are bound by the bytes of the rows they gather, so the projected features can be kept
  * as bfloat16 rows (same head-padded layout, 2 bytes per channel): gatmi_attn.feat_bf16 = 1 and

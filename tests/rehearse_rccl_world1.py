@@ -59,16 +59,22 @@ def main():
               f"worst relative grad err {gerr:.2e}", flush=True)
         # every exchange mode of one layer against the single-GPU layer
         bf = torch.bfloat16
-        for mode, f, h, c, xg, dt in (("h", 64, 4, 16, True, None), ("x", 12, 4, 16, True, None),
-                                      ("xs", 12, 4, 16, False, None), ("as", 12, 4, 16, False, None),
-                                      ("h", 256, 4, 64, True, None), ("xs", 100, 4, 64, False, bf),
-                                      ("as", 100, 4, 64, False, bf), ("as", 100, 8, 32, False, bf)):
+        # the last four: exchange "h" in pieces (asynchronous all_gather_into_tensor / reduce_scatter_tensor
+        # per piece with the attention of the arrived pieces in between), and on exact tables (per-owner
+        # broadcast / reduce)
+        for mode, f, h, c, xg, dt, chunks, padding in (
+                ("h", 64, 4, 16, True, None, 1, "auto"), ("x", 12, 4, 16, True, None, 1, "auto"),
+                ("xs", 12, 4, 16, False, None, 1, "auto"), ("as", 12, 4, 16, False, None, 1, "auto"),
+                ("h", 256, 4, 64, True, None, 1, "auto"), ("xs", 100, 4, 64, False, bf, 1, "auto"),
+                ("as", 100, 4, 64, False, bf, 1, "auto"), ("as", 100, 8, 32, False, bf, 1, "auto"),
+                ("h", 64, 4, 16, True, None, 3, "pad"), ("h", 256, 4, 64, True, None, 4, "pad"),
+                ("h", 256, 8, 32, True, None, 2, "exact"), ("x", 12, 4, 16, True, None, 1, "exact")):
             torch.manual_seed(11)
             # bf16 rows: both sides on the input-side path (GATConv alone would pick by a cost model)
             one = GATConv(f, c, heads=h, dropout=0.0, feature_dtype=dt,
                           input_aggregation=True if dt is not None else None).to(dev)
-            many = PartitionedGATConv(f, c, heads=h, dropout=0.0, exchange=mode,
-                                      feature_dtype=dt).to(dev)
+            many = PartitionedGATConv(f, c, heads=h, dropout=0.0, exchange=mode, feature_dtype=dt,
+                                      chunks=chunks, padding=padding).to(dev)
             many.load_state_dict(one.state_dict())
             xa = torch.randn(n, f, device=dev, requires_grad=xg)
             xb = xa.detach().clone().requires_grad_(xg)
@@ -84,8 +90,25 @@ def main():
             e_x = float((xa.grad - xb.grad).abs().max() / xa.grad.abs().max()) if xg else 0.0
             good = e_out < 1e-5 and e_w < 1e-4 and e_x < 1e-4
             ok &= good
-            print(f"{'ok' if good else 'FAILED'} exchange={mode} {f}->{h}x{c}{' bf16 rows' if dt is not None else ''}: out {e_out:.1e} d_W {e_w:.1e} d_x {e_x:.1e}",
-                  flush=True)
+            print(f"{'ok' if good else 'FAILED'} exchange={mode} {f}->{h}x{c}{' bf16 rows' if dt is not None else ''}"
+                  f"{f' in {chunks} pieces' if chunks > 1 else ''}{' exact tables' if padding == 'exact' else ''}: "
+                  f"out {e_out:.1e} d_W {e_w:.1e} d_x {e_x:.1e}", flush=True)
+        # a bf16 table in pieces against the same table in one piece
+        torch.manual_seed(13)
+        one = PartitionedGATConv(256, 64, heads=4, dropout=0.0, exchange="h", feature_dtype=bf, chunks=1).to(dev)
+        many = PartitionedGATConv(256, 64, heads=4, dropout=0.0, exchange="h", feature_dtype=bf, chunks=3).to(dev)
+        many.load_state_dict(one.state_dict())
+        xa = torch.randn(n, 256, device=dev, requires_grad=True)
+        xb = xa.detach().clone().requires_grad_(True)
+        go = torch.randn(n, 256, device=dev)
+        oa = one(xa, eid, n); oa.backward(go)
+        ob = many(xb, eid, n); ob.backward(go)
+        e_out = float((oa.detach() - ob.detach()).abs().max() / oa.detach().abs().max())
+        e_x = float((xa.grad - xb.grad).norm() / xa.grad.norm())
+        good = e_out < 1e-5 and e_x < 2e-3
+        ok &= good
+        print(f"{'ok' if good else 'FAILED'} exchange=h 256->4x64 bf16 table in 3 pieces vs 1: out {e_out:.1e} "
+              f"d_x (relative L2) {e_x:.1e}", flush=True)
         dist.barrier()
         torch.cuda.synchronize()
     finally:

@@ -53,6 +53,70 @@ class OracleBackend:
         d_att_dst = (d_a_dst.unsqueeze(-1) * h_loc).sum(0).reshape(-1)
         return leaves[0].grad, leaves[2].grad, d_att_dst, leaves[3].grad, d_a_dst
 
+    # ---- source chunks (exchange "h" in pieces): the closed forms of SURVEY.md 8a row a11
+    def build_chunk_layout(self, edges, num_src, num_dst):
+        return dict(ei=edges, num_src=num_src, num_dst=num_dst, num_edges=edges.size(1))
+
+    def attn_fwd_partial(self, layout, cfg, f, hp_piece, a_dst, att_s):
+        h_, c_, n = cfg.heads, cfg.channels, layout["num_dst"]
+        src, dst = layout["ei"][0], layout["ei"][1]
+        assert hp_piece.size(0) == layout["num_src"]
+        hh = hp_piece.view(-1, h_, c_)
+        a_s = (hh * att_s.view(1, h_, c_)).sum(-1)
+        z = torch.nn.functional.leaky_relu(a_s[src] + a_dst[dst], cfg.negative_slope)
+        m = torch.full((n, h_), -float("inf"), dtype=z.dtype).scatter_reduce_(
+            0, dst.view(-1, 1).expand(-1, h_), z, "amax", include_self=True)
+        p = torch.exp(z - m[dst])
+        s = torch.zeros(n, h_, dtype=z.dtype).index_add_(0, dst, p)
+        acc = torch.zeros(n, h_, c_, dtype=z.dtype).index_add_(0, dst, p.unsqueeze(-1) * hh[src])
+        return m, s, acc.view(n, h_ * c_)
+
+    def attn_fwd_combine(self, parts, cfg, bias, need_lse):
+        h_, c_ = cfg.heads, cfg.channels
+        big = torch.stack([m for m, _, _ in parts]).max(0).values
+        tot, acc = 0, 0
+        for m, s, a in parts:
+            f = torch.where(torch.isinf(m), torch.zeros_like(m), torch.exp(m - big))
+            tot = tot + s * f
+            acc = acc + f.unsqueeze(-1) * a.view(-1, h_, c_)
+        out = (acc / tot.unsqueeze(-1)).reshape(-1, h_ * c_)
+        return (out + bias if bias is not None else out), big + torch.log(tot)
+
+    def chunked_backward(self, cfg, f, a_dst, att_s, att_d, bias, out, lse, grad_out, max_chunks):
+        be = self
+
+        class _CB:
+            def __init__(self):
+                h_, c_ = cfg.heads, cfg.channels
+                self.g = grad_out.view(-1, h_, c_)
+                o = out if bias is None else out - bias
+                self.S = (self.g * o.view(-1, h_, c_)).sum(-1)
+                self.d_a_dst = torch.zeros_like(a_dst)
+                self.d_att_src = torch.zeros(h_, c_, dtype=a_dst.dtype)
+
+            def chunk(self, k, layout, cfg_k, hp_piece):
+                h_, c_ = cfg.heads, cfg.channels
+                src, dst = layout["ei"][0], layout["ei"][1]
+                hh = hp_piece.view(-1, h_, c_)
+                a_s = (hh * att_s.view(1, h_, c_)).sum(-1)
+                u = a_s[src] + a_dst[dst]
+                alpha = torch.exp(torch.nn.functional.leaky_relu(u, cfg.negative_slope) - lse[dst])
+                d_at = (self.g[dst] * hh[src]).sum(-1)
+                du = (alpha * d_at - alpha * self.S[dst]) * torch.where(u > 0, torch.ones_like(u), torch.full_like(u, cfg.negative_slope))
+                d_h = torch.zeros_like(hh).index_add_(0, src, alpha.unsqueeze(-1) * self.g[dst])
+                d_a_src = torch.zeros_like(a_s).index_add_(0, src, du)
+                d_h += d_a_src.unsqueeze(-1) * att_s.view(1, h_, c_)
+                self.d_a_dst.index_add_(0, dst, du)
+                self.d_att_src += (d_a_src.unsqueeze(-1) * hh).sum(0)
+                return d_h.view(hp_piece.size(0), -1)
+
+            def end(self, hp_own):
+                h_, c_ = cfg.heads, cfg.channels
+                d_ad = (self.d_a_dst.unsqueeze(-1) * hp_own.view(-1, h_, c_)).sum(0).reshape(-1)
+                return self.d_att_src.reshape(-1), d_ad, grad_out.sum(0), self.d_a_dst
+
+        return _CB()
+
     def add_dst_term(self, d_hp, d_a_dst, att_d, cfg):
         d_hp.view(-1, cfg.heads, cfg.channels).add_(
             d_a_dst.unsqueeze(-1) * att_d.view(1, cfg.heads, cfg.channels))
@@ -104,7 +168,7 @@ class OracleBackend:
         return wl.grad, asl.grad, adl.grad, bl.grad
 
 
-def _worker(rank, world, port, n, gname, exchange, balance, q):
+def _worker(rank, world, port, n, gname, exchange, balance, q, chunks=1, padding="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -114,8 +178,9 @@ def _worker(rank, world, port, n, gname, exchange, balance, q):
         f, h, c = 6, 3, 5
         x, w, a_s, a_d, b, go = [t.double() for t in cases.layer_inputs(n_, f, h, c)]
         conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend(), exchange=exchange,
-                                  balance=balance).double().eval()
+                                  balance=balance, chunks=chunks, padding=padding).double().eval()
         part = conv.partition_for(ei, n_)
+        assert part.uneven == (padding == "exact") or padding == "auto"
         if balance == "edges" and gname == "star":      # the hub's range is much shorter than the rest
             assert part.bounds is not None and part.bounds[1] < n_ // world
         with torch.no_grad():
@@ -151,10 +216,10 @@ def _worker(rank, world, port, n, gname, exchange, balance, q):
         dist.destroy_process_group()
 
 
-def _run(world, n, gname, exchange, port, balance="nodes"):
+def _run(world, n, gname, exchange, port, balance="nodes", chunks=1, padding="auto"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gname, exchange, balance, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, gname, exchange, balance, q, chunks, padding))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -183,6 +248,57 @@ def test_partitioned_layer_with_edge_balanced_ranges(world, n, gname, exchange, 
     _run(world, n, gname, exchange, port, balance="edges")
 
 
+@pytest.mark.parametrize("world,n,gname,balance,chunks,padding,port", [
+    (2, 50, None, "nodes", 2, "pad", 29661), (3, 50, None, "edges", 3, "pad", 29662),
+    (2, None, "star", "edges", 4, "pad", 29663), (3, None, "hub_source", "edges", 2, "exact", 29664),
+    (3, 7, None, "nodes", 4, "pad", 29665), (2, 51, None, "edges", 3, "exact", 29666),
+    (4, 9, None, "edges", 4, "exact", 29667)])
+def test_pipelined_exchange_equals_single_process(world, n, gname, balance, chunks, padding, port):
+    """Exchange "h" in pieces: the all-gather of h issued as one asynchronous
+    collective per piece, attention over the sources of piece k from a layout of its own, the
+    (m, s, acc) triples joined at the end; backward per piece with its reduce-scatter in flight --
+    output and every gradient equal the single-process oracle, on padded (equal-shard collectives)
+    and exact (per-owner broadcasts / reductions) tables, incl. pieces that hold no rows (7 nodes
+    over 3 ranks in 4 pieces) and ranks that own none."""
+    _run(world, n, gname, "h", port, balance, chunks, padding)
+
+
+@pytest.mark.parametrize("world,n,gname,exchange,port", [
+    (2, 50, None, "h", 29671), (3, None, "star", "as", 29672), (3, 50, None, "x", 29673),
+    (2, 51, None, "xs", 29674)])
+def test_partitioned_layer_on_exact_tables(world, n, gname, exchange, port):
+    """padding="exact": tables of exactly N rows indexed by global id, per-owner collectives --
+    every one-piece exchange mode."""
+    _run(world, n, gname, exchange, port, "edges", 1, "exact")
+
+
+def test_padding_is_bounded_on_a_degree_ordered_graph():
+    """on a power-law graph whose nodes are ordered by degree the edge-balanced
+    range that holds the low-degree tail is several times N / P long; padding every shard to it
+    would multiply the collectives' volume and the gathered table.  make_partition then switches to
+    exact tables (ratio 1.0); a graph whose ranges are near-equal keeps the equal-shard form."""
+    from gat_amd import synth
+    from gat_amd.dist import PAD_LIMIT, make_partition
+    n, e, world = 20000, 300000, 8
+    ei = synth.powerlaw_graph(n, e, 4000, seed=3)
+    order = torch.argsort(torch.bincount(ei[1], minlength=n), descending=True)
+    rank_of = torch.empty_like(order); rank_of[order] = torch.arange(n)
+    skewed = rank_of[ei]
+    padded = make_partition(skewed, n, world, 0, padding="pad")
+    assert padded.padding_ratio > 2.0, padded.padding_ratio        # what round 2 moved
+    auto = make_partition(skewed, n, world, 0)
+    assert auto.uneven and auto.padding_ratio == 1.0 and auto.padded_nodes == n
+    for k in (1, 4):
+        tm = auto.table(k)
+        assert tm.total == n                                        # no padding rows in any piece
+        rows = tm.to_table(torch.arange(n))
+        assert rows.unique().numel() == n and int(rows.max()) == n - 1
+    mild = make_partition(ei, n, world, 0)                          # hubs spread over the id range
+    assert not mild.uneven and mild.padding_ratio <= PAD_LIMIT
+    for k in (1, 2, 3, 4):                                          # pieces are padded to ceil(block / k)
+        assert mild.table(k).total <= mild.world * (mild.block + k)
+
+
 def test_balanced_bounds_split_the_in_edges_evenly():
     from gat_amd import synth
     from gat_amd.dist import Partition, balanced_bounds, local_edges, make_partition
@@ -201,7 +317,7 @@ def test_balanced_bounds_split_the_in_edges_evenly():
     assert max(per_edges) <= 1.05 * total / world + 4000      # within 5 % + one hub row
     assert max(per_nodes) > 2 * total / world                 # what equal blocks would have given
     # padded ids: a bijection of the nodes into [0, world * block), rank-major
-    part = make_partition(ei, n, world, 3)
+    part = make_partition(ei, n, world, 3, padding="pad")
     assert part.bounds == bounds
     pid = part.to_padded(torch.arange(n))
     assert pid.unique().numel() == n and int(pid.max()) < part.padded_nodes
