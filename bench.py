@@ -30,7 +30,7 @@ def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/
     (bench.py cannot collect counters itself: this is a RECORDED figure of the same command, not
     one measured in this run) -> (bytes or None, where it came from)."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         try:
             with open(path) as f:
@@ -97,6 +97,12 @@ def main():
                     help="N>1: what the destination partition all-gathers (gat_amd/dist.py)")
     ap.add_argument("--partition", default="edges", choices=["edges", "nodes"],
                     help="N>1: destination ranges of equal in-edge count (SURVEY.md 8e) or equal node count")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N>1, exchange h: pieces the table travels in, attention over piece k overlapping the "
+                         "collective of piece k+1 (0: 4 when N > 1, else 1)")
+    ap.add_argument("--padding", default="auto", choices=["auto", "pad", "exact"],
+                    help="N>1: gathered tables padded to the longest range (equal-shard collectives) or exact "
+                         "(per-owner collectives); auto: exact when padding exceeds 1.25 rows per node")
     ap.add_argument("--no-exchange-h", action="store_true",
                     help="N>1: skip the second timed region (exchange=h, the north_star's all-gather of "
                          "projected features) that is reported next to --exchange auto")

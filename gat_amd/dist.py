@@ -599,13 +599,15 @@ class _PartitionedFn(torch.autograd.Function):
         bias_c = None if bias is None else bias.contiguous()
         f = x_local.size(1)
         if exchange == "x":
-            x_full = gather_rows(x_local, part, group)
+            with _Timed("allgather_x", x_local):
+                x_full = gather_rows(x_local, part, group)
             hp_full, a_dst_full = be.project_fwd(x_full, weight, att_d, cfg)
             a_dst = a_dst_full[part.plo:part.phi].contiguous()
             x_saved = x_full
         else:
             hp_local, a_dst = be.project_fwd(x_local, weight, att_d, cfg)
-            hp_full = gather_rows(hp_local, part, group)
+            with _Timed("allgather_h", hp_local):
+                hp_full = gather_rows(hp_local, part, group)
             x_saved = x_local
         need_grad = any(ctx.needs_input_grad[:5])
         out, lse = be.attn_fwd(layout, cfg, f, hp_full, a_dst, att_s, att_d, bias_c, need_grad)
@@ -628,13 +630,16 @@ class _PartitionedFn(torch.autograd.Function):
             d_w, d_x_part = be.project_bwd(x_saved, weight, d_hp_part, cfg, need_dx)
             d_x = None
             if need_dx:
-                d_x = scatter_rows(d_x_part, part, group)
+                with _Timed("reduce_scatter_dx", d_x_part):
+                    d_x = scatter_rows(d_x_part, part, group)
         else:
-            d_hp = scatter_rows(d_hp_part, part, group)
+            with _Timed("reduce_scatter_dh", d_hp_part):
+                d_hp = scatter_rows(d_hp_part, part, group)
             d_hp = d_hp.contiguous()
             be.add_dst_term(d_hp, d_a_dst, att_d, cfg)
             d_w, d_x = be.project_bwd(x_saved, weight, d_hp, cfg, need_dx)
-        all_reduce_many([d_w, d_as, d_ad, d_b], group)
+        with _Timed("allreduce_params", d_w):
+            all_reduce_many([d_w, d_as, d_ad, d_b], group)
         return (d_x, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
                 None, None, None, None, None, None)
 
@@ -756,7 +761,8 @@ class _PartitionedInAggFn(torch.autograd.Function):
         bias_c = None if bias is None else bias.contiguous()
         xs_local, a_dst = be.inagg_pack(x_local, weight, att_s, att_d, cfg)
         if exchange == "xs":
-            table = gather_rows(xs_local, part, group)
+            with _Timed("allgather_xs", xs_local):
+                table = gather_rows(xs_local, part, group)
         else:
             c0, cn = be.inagg_logit_columns(x_local.size(1), cfg)
             # The cached table is valid for THIS x tensor object at THIS version only: a pointer
@@ -773,7 +779,8 @@ class _PartitionedInAggFn(torch.autograd.Function):
                 cache["owner"], cache["version"] = weakref.ref(x_local), x_local._version
                 cache["world"], cache["bounds"] = part.world, (part.bounds, part.uneven)
             else:                             # later calls: only the logits travel
-                logits = gather_rows(xs_local[:, c0:c0 + cn].contiguous(), part, group)
+                with _Timed("allgather_a_src", xs_local):
+                    logits = gather_rows(xs_local[:, c0:c0 + cn].contiguous(), part, group)
                 cache["table"][:, c0:c0 + cn] = logits
             table = cache["table"]
         # bf16 copy of the table for the edge kernels' gathers (cfg.rows16).  Exchange "as": its x
@@ -806,7 +813,8 @@ class _PartitionedInAggFn(torch.autograd.Function):
         kw = {} if xs16 is None else {"xs16": xs16}
         d_w, d_as, d_ad, d_b = be.inagg_bwd(layout, cfg, table, a_dst, weight, att_s, att_d, bias_c,
                                             z, lse, grad_out.contiguous(), **kw)
-        all_reduce_many([d_w, d_as, d_ad, d_b], group)
+        with _Timed("allreduce_params", d_w):
+            all_reduce_many([d_w, d_as, d_ad, d_b], group)
         return (None, d_w, d_as.view(att_shape), d_ad.view(att_shape), d_b,
                 None, None, None, None, None, None, None)
 
@@ -1045,7 +1053,8 @@ EXCHANGE_TEXT = {
 
 def _timed_steps(step, steps, warmup, dev):
     """bench.py's contract: warm-up, then exactly `steps` steps between barrier + synchronize on
-    both sides, MAX over ranks.  -> (seconds, {kernel tag: mean ms on this rank})"""
+    both sides, MAX over ranks.  -> (seconds, {kernel tag: mean ms on this rank},
+    {collective: mean ms per step this rank's stream spent in / waiting for it})"""
     for _ in range(warmup):
         step()
     _lib.prof_read()
@@ -1053,6 +1062,7 @@ def _timed_steps(step, steps, warmup, dev):
     dist.barrier()
     torch.cuda.synchronize()
     _lib.prof_enable(True)          # per-kernel HIP events, as in the single-GPU run
+    comm_timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -1061,11 +1071,32 @@ def _timed_steps(step, steps, warmup, dev):
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     _lib.prof_enable(False)
+    comm = {k: round(v / steps, 4) for k, v in sorted(comm_ms_read().items())}
+    comm_timing(False)
     all_reduce_(el, op=dist.ReduceOp.MAX)
     per = {}
     for tag, ms in _lib.prof_read():
         per.setdefault(tag, []).append(ms)
-    return float(el.item()), {k: sum(v) / len(v) for k, v in per.items()}
+    # a kernel launched once per piece shows up `pieces` times per step: report its per-step total
+    return float(el.item()), {k: sum(v) / steps for k, v in per.items()}, comm
+
+
+def _recorded_traffic_ratio(workload: str, kernel: str, full_alg_bytes):
+    """HBM traffic / algorithmic bytes of `kernel` from the committed one-GPU PMC passes
+    (profiles/rN/pmc_traffic.json; full_alg_bytes = the kernel's algorithmic bytes on the whole
+    graph, what those passes ran on) -> (ratio or None, source)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = workload[:-len("_hidden")] if workload.endswith("_hidden") else workload
+    for rnd in ("r3", "r2", "r1"):
+        path = os.path.join(root, "profiles", rnd, "pmc_traffic.json")
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("workload") == base and t["kernels"].get(kernel) and full_alg_bytes:
+                return t["kernels"][kernel] / full_alg_bytes, f"profiles/{rnd}/pmc_traffic.json"
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def bench_partitioned(args, rank: int, world: int, dev) -> None:
@@ -1073,26 +1104,35 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     bench.py's JSON line.  Every rank regenerates the same graph from the seed and keeps
     its own destination range.  `value` is the mode --exchange names (auto: what the layer picks
     by itself); the line also carries the north_star's own pattern -- all-gather of the projected
-    features + all-reduce of the weight gradients, exchange="h" -- timed the same way, under
-    "exchange_h"."""
+    features + all-reduce of the weight gradients, exchange="h" -- timed the same way: in pieces
+    with the attention overlapping the collectives ("exchange_h") and as one blocking collective
+    per direction ("exchange_h_one_piece"), each with the time spent in its collectives."""
     from . import synth
     from .ops import AttnConfig
     ei, n, f, h, c = synth.workload_graph(args.workload, args.seed, dev)
     balance = getattr(args, "partition", "edges")
-    part = make_partition(ei, n, world, rank, balance)
+    padding = getattr(args, "padding", "auto")
+    chunks = int(getattr(args, "chunks", 0) or 0)
+    part = make_partition(ei, n, world, rank, balance, padding)
     g = torch.Generator(device=dev).manual_seed(args.seed)
     x = torch.randn(n, f, generator=g, device=dev)[part.lo:part.hi].contiguous()
     go = torch.randn(n, h * c, generator=g, device=dev)[part.lo:part.hi].contiguous()
     hidden = args.workload.endswith("_hidden")
     x.requires_grad_(hidden)
     torch.manual_seed(args.seed)
-    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout, balance=balance,
-                              exchange=getattr(args, "exchange", "auto"),
-                              feature_dtype=torch.bfloat16 if getattr(args, "dtype", "f32") == "bf16" else None
-                              ).to(dev).train()
+    bf16 = getattr(args, "dtype", "f32") == "bf16"
+    conv = PartitionedGATConv(f, c, heads=h, dropout=args.dropout, balance=balance, padding=padding,
+                              exchange=getattr(args, "exchange", "auto"), chunks=chunks,
+                              feature_dtype=torch.bfloat16 if bf16 else None).to(dev).train()
+    mode = conv.resolve_exchange(x, AttnConfig(h, c))
+    pieces = conv.pieces(part) if mode == "h" else 1
     torch.cuda.synchronize()
     t0 = time.time()
-    layout = conv.layout_for(ei, part)
+    if mode == "h" and pieces > 1:
+        layouts = conv.piece_layouts_for(ei, part, part.table(pieces))
+        n_edges = sum(l.num_edges for l in layouts if l is not None)
+    else:
+        n_edges = conv.layout_for(ei, part).num_edges
     torch.cuda.synchronize()
     t_layout = time.time() - t0
     # every rank's (edges, nodes): one all-reduce of a [world, 2] table with the own row filled in.
@@ -1100,11 +1140,10 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
     # set-up must not happen inside the backward (autograd's thread), where the first all-reduce
     # of a gloo rehearsal was seen to hang.
     shares = torch.zeros(world, 2, device=dev, dtype=torch.int64)
-    shares[rank, 0], shares[rank, 1] = layout.num_edges, part.n_local
+    shares[rank, 0], shares[rank, 1] = n_edges, part.n_local
     all_reduce_(shares)
     shares = shares.tolist()
     ep = int(sum(s[0] for s in shares))
-    mode = conv.resolve_exchange(x, AttnConfig(h, c))
 
     trace = bool(os.environ.get("GAT_TRACE"))
 
@@ -1120,34 +1159,62 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
             torch.cuda.synchronize()
             print(f"[rank {rank}] {time.time() % 1000:.2f} backward done", file=sys.stderr, flush=True)
 
-    elapsed, avg = _timed_steps(step, args.steps, args.warmup, dev)
+    def region(mode_, pieces_):
+        """time one exchange mode -> dict for the line"""
+        conv.exchange, conv.chunks = mode_, pieces_
+        conv._table_cache.clear()
+        el, avg_, comm_ = _timed_steps(step, args.steps, args.warmup, dev)
+        fb = 2 if ("proj16_fwd_gemm" in avg_ or (bf16 and mode_ in ("xs", "as")
+                   and conv.backend.inagg_rows16_supported(f, AttnConfig(h, c)))) else 4
+        dp = h * ((c + 3) // 4 * 4)
+        width = {"h": dp * fb, "x": f * 4, "xs": (-(-f // 4) * 4 + -(-h // 4) * 4) * 4, "as": -(-h // 4) * 4 * 4}[mode_]
+        tm_ = part.table(pieces_)
+        return {"exchange": mode_, "pieces": pieces_, "ms_per_step": round(el / args.steps * 1e3, 4),
+                "value": ep / (el / args.steps), "unit": "edges/s", "parallelism": EXCHANGE_TEXT[mode_],
+                "comm_ms": comm_, "comm_ms_total": round(sum(comm_.values()), 4),
+                "comm_note": "milliseconds per step this rank's compute stream spent inside / waiting for each "
+                             "collective (HIP events around it); with pieces > 1 the wait_* entries are what the "
+                             "overlap did NOT hide",
+                "gathered_table": {"rows": tm_.total, "rows_per_node": round(tm_.total / max(n, 1), 4),
+                                   "bytes": tm_.total * width,
+                                   "received_bytes_per_rank_fwd": (tm_.total - sum(tm_.cap[s][rank] for s in range(pieces_))) * width},
+                "kernels": {k: {"avg_ms": round(v, 4)} for k, v in sorted(avg_.items())},
+                "_avg": avg_, "_fb": fb}
+
+    main_r = region(mode, pieces)
+    avg = main_r["_avg"]
     # roofline of rank 0's dominant kernel on ITS share: local destination rows, local edges
-    rows16 = (getattr(args, "dtype", "f32") == "bf16" and mode in ("xs", "as")
-              and conv.backend.inagg_rows16_supported(f, AttnConfig(h, c)))
-    kb = synth.kernel_bytes(part.n_local, layout.num_edges, h, h * c, f,
-                            feat_bytes=2 if (rows16 or "proj16_fwd_gemm" in avg) else 4)
+    kb = synth.kernel_bytes(part.n_local, int(shares[rank][0]), h, h * c, f, feat_bytes=main_r["_fb"])
     roofline = None
     if any(k in avg for k in kb):
         dom = max(kb, key=lambda k: avg.get(k, 0.0))
         achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
+        full = synth.kernel_bytes(n, ep, h, h * c, f, feat_bytes=main_r["_fb"]).get(dom)
+        ratio, src = _recorded_traffic_ratio(args.workload, dom + ("_bf16" if main_r["_fb"] == 2 else ""), full)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                    "traffic": None if ratio is None else int(kb[dom] * ratio),
+                    "traffic_source": None if ratio is None else
+                    f"{src}: traffic / algorithmic bytes of this kernel in the recorded one-GPU rocprofv3 --pmc "
+                    f"passes ({ratio:.3f}) applied to this rank's algorithmic bytes; not measured in this run",
                     "avg_ms": round(avg[dom], 4), "algorithmic_bytes": kb[dom],
-                    "scope": f"rank 0 of {world}: {part.n_local} destination rows, {layout.num_edges} edges"}
-    other = None
-    if mode != "h" and not getattr(args, "no_exchange_h", False):
-        conv.exchange = "h"
-        conv._table_cache.clear()
-        el_h, avg_h = _timed_steps(step, args.steps, args.warmup, dev)
-        other = {"ms_per_step": round(el_h / args.steps * 1e3, 4), "value": ep / (el_h / args.steps),
-                 "unit": "edges/s", "parallelism": EXCHANGE_TEXT["h"],
-                 "kernels": {k: {"avg_ms": round(v, 4)} for k, v in sorted(avg_h.items())}}
+                    "scope": f"rank 0 of {world}: {part.n_local} destination rows, {int(shares[rank][0])} edges"
+                             + (f"; {main_r['pieces']} launches per step (one per piece), avg_ms is their sum"
+                                if main_r["pieces"] > 1 else "")}
+    others = {}
+    if not getattr(args, "no_exchange_h", False):
+        hp = chunks or (4 if world > 1 else 1)
+        if not (mode == "h" and pieces == hp):
+            others["exchange_h"] = region("h", hp)
+        if hp > 1 and not (mode == "h" and pieces == 1):
+            others["exchange_h_one_piece"] = region("h", 1)
     if rank == 0:
-        res = {"metric": "GAT layer fwd+bwd edges/sec", "value": ep / (elapsed / args.steps),
+        strip = lambda d: {k: v for k, v in d.items() if not k.startswith("_")}
+        res = {"metric": "GAT layer fwd+bwd edges/sec", "value": main_r["value"],
                "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+               "ms_per_step": main_r["ms_per_step"], "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None,
-               "dtype": "bf16" if ("proj16_fwd_gemm" in avg or rows16) else "f32", "data": "synthetic",
+               "dtype": "bf16" if main_r["_fb"] == 2 else "f32", "data": "synthetic",
                "config": {"workload": f"{args.workload}-shaped synthetic graph: {n} nodes, "
                                       f"{ei.size(1)} edges ({ep} after self-loop normalisation), one GAT "
                                       f"layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
@@ -1155,14 +1222,33 @@ def bench_partitioned(args, rank: int, world: int, dev) -> None:
                           "nodes": n, "edges": ep, "in_features": f, "heads": h, "channels": c,
                           "parallelism": f"destination partition x{world} (ranges balanced by "
                                          f"{'in-edge' if balance == 'edges' else 'node'} count), "
-                                         f"exchange={mode}: " + EXCHANGE_TEXT[mode] + f", {dist.get_backend()}",
+                                         f"exchange={mode}"
+                                         + (f" in {pieces} pieces, attention overlapped with the collectives" if pieces > 1 else "")
+                                         + ": " + EXCHANGE_TEXT[mode] + f", {dist.get_backend()}",
                           "partition": {"balance": balance,
+                                        "tables": "exact (per-owner collectives)" if part.uneven else
+                                                  "padded to the longest range (equal-shard collectives)",
+                                        "padded_nodes_over_n": round(part.padding_ratio, 4),
                                         "edges_per_rank": [int(s[0]) for s in shares],
                                         "nodes_per_rank": [int(s[1]) for s in shares]},
                           "graph_layout_build_s": round(t_layout, 4)},
                "roofline": roofline,
-               "kernels": {k: {"avg_ms": round(v, 4)} for k, v in sorted(avg.items())},
-               "exchange_h": other,
-               "cpu_baseline": None}
-        print(json.dumps(res))
+               "pieces": main_r["pieces"],
+               "comm_ms": main_r["comm_ms"], "comm_ms_total": main_r["comm_ms_total"],
+               "gathered_table": main_r["gathered_table"],
+               "kernels": main_r["kernels"]}
+        res.update({k: strip(v) for k, v in others.items()})
+    dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        # the reference's CPU path next to it (north_star): the oracle on this host's cores, after the
+        # process group is gone so that no rank waits in a collective meanwhile
+        res["cpu_baseline"] = None
+        if not getattr(args, "no_cpu_baseline", False):
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            if root not in sys.path:
+                sys.path.insert(0, root)
+            import bench as _bench
+            res["cpu_baseline"] = _bench.cpu_baseline(args.workload[:-len("_hidden")] if hidden else args.workload,
+                                                      args.seed, budget_s=15.0)
+        print(json.dumps(res))

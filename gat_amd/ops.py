@@ -29,6 +29,22 @@ def padded_channels(channels: int) -> int:
     return (channels + 3) // 4 * 4
 
 
+def _expect(t: Optional[Tensor], shape, dtype, name: str, dev=None) -> None:
+    """Host-side operand check before a kernel launch: the kernels index by the sizes the
+    descriptors state and do no bounds tests of their own, so a tensor that is shorter than stated
+    would be a device memory fault, not an exception."""
+    if t is None:
+        return
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if not t.is_cuda or (dev is not None and t.device != dev):
+        raise RuntimeError(f"{name} must be a tensor on {dev or 'the GPU'} (got {t.device}); gat_amd has no CPU path")
+
+
 class AttnConfig:
     """Everything the fused attention kernels need besides tensors."""
 
@@ -40,7 +56,24 @@ class AttnConfig:
         self.stream = 0     # input-side aggregation forward: 0 auto, 1 streaming, 2 registers
         self.feat_bf16 = False   # projected-row path: hp is a bfloat16 table (attn_bf16_supported)
 
-    def c_args(self, num_dst, in_features, hp, a_dst, att_src, att_dst, bias):
+    def c_args(self, num_dst, in_features, hp, a_dst, att_src, att_dst, bias, num_src=None, num_edges=None):
+        dev = a_dst.device
+        hc = self.heads * self.channels
+        if hp is not None:
+            rows = hp.size(0) if num_src is None else num_src
+            _expect(hp, (rows, self.heads * padded_channels(self.channels)),
+                    torch.bfloat16 if self.feat_bf16 else torch.float32, "feature table", dev)
+        _expect(a_dst, (num_dst, self.heads), torch.float32, "a_dst", dev)
+        for name, t in (("att_src", att_src), ("att_dst", att_dst), ("bias", bias)):
+            if t is not None:
+                _expect(t.view(-1), (hc,), torch.float32, name, dev)
+        if self.mask_mode == _lib.MASK_BYTES:
+            if self.mask is None or num_edges is None:
+                raise ValueError("mask_mode BYTES needs a mask and the layout's edge count")
+            _expect(self.mask, (num_edges, self.heads), torch.uint8, "dropout mask", dev)
+        if self.mask_mode == _lib.MASK_HASH_DEV:
+            if self.mask is None or self.mask.numel() != 1 or self.mask.dtype != torch.int64 or not self.mask.is_cuda:
+                raise ValueError("mask_mode HASH_DEV needs a one-element int64 device tensor (the seed)")
         a = _lib.Attn()
         a.shape = _lib.Shape(num_dst, in_features, self.heads, self.channels)
         a.negative_slope, a.dropout_p = self.negative_slope, self.dropout
@@ -63,12 +96,24 @@ def _alloc_table(n: int, cols: int, dtype, dev, alloc_rows: Optional[int]) -> Te
     return t
 
 
+def _project_operands(x, weight, att_dst, heads, channels, d_hp=None, d_a_dst=None):
+    n, f = x.shape
+    dev = x.device
+    _expect(x, (n, f), torch.float32, "x", dev)
+    _expect(weight, (heads * channels, f), torch.float32, "weight", dev)
+    if att_dst is not None:
+        _expect(att_dst.view(-1), (heads * channels,), torch.float32, "att_dst", dev)
+    _expect(d_hp, (n, heads * padded_channels(channels)), torch.float32, "d_hp", dev)
+    _expect(d_a_dst, (n, heads), torch.float32, "d_a_dst", dev)
+
+
 def project_fwd(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, channels: int,
                 alloc_rows: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     """h = lin(x) in the head-padded layout [N, H*Cp] and a_dst [N, H].  alloc_rows: the table is
     allocated with that many rows (>= N; the extra rows are zero)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
+    _project_operands(x, weight, att_dst, heads, channels)
     shape = _lib.Shape(n, f, heads, channels)
     with torch.cuda.device(dev):
         hp = _alloc_table(n, heads * padded_channels(channels), torch.float32, dev, alloc_rows)
@@ -87,6 +132,7 @@ def project_bwd(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channels: i
     d_hp is added while its tiles are staged (see gatmi_project_bwd)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
+    _project_operands(x, weight, att_dst, heads, channels, d_hp, d_a_dst)
     shape = _lib.Shape(n, f, heads, channels)
     with torch.cuda.device(dev):
         d_w = torch.empty_like(weight)
@@ -110,6 +156,7 @@ def project_fwd_bf16(x: Tensor, weight: Tensor, att_dst: Tensor, heads: int, cha
     """bf16 MFMA projection: the bfloat16 feature table [N, H*Cp] and a_dst [N, H] (f32)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
+    _project_operands(x, weight, att_dst, heads, channels)
     shape = _lib.Shape(n, f, heads, channels)
     with torch.cuda.device(dev):
         hp16 = _alloc_table(n, heads * padded_channels(channels), torch.bfloat16, dev, alloc_rows)
@@ -128,6 +175,7 @@ def project_bwd_bf16(x: Tensor, weight: Tensor, d_hp: Tensor, heads: int, channe
     """d_weight, d_x of the projection on the bf16 matrix cores (operands rounded, f32 sums)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
+    _project_operands(x, weight, att_dst, heads, channels, d_hp, d_a_dst)
     shape = _lib.Shape(n, f, heads, channels)
     with torch.cuda.device(dev):
         d_w = torch.empty_like(weight)
@@ -147,7 +195,7 @@ def attn_fwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor,
     lib, dev = _lib.lib(), hp.device
     n = layout.num_dst
     with torch.cuda.device(dev):
-        a = cfg.c_args(n, in_features, hp, a_dst, att_src, att_dst, bias)
+        a = cfg.c_args(n, in_features, hp, a_dst, att_src, att_dst, bias, layout.num_nodes, layout.num_edges)
         out = torch.empty(n, cfg.heads * cfg.channels, dtype=torch.float32, device=dev)
         lse = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev) if need_lse else None
         ws = _ws(lib.gatmi_attn_fwd_workspace_bytes(layout.ref, C.byref(a.shape)), dev)
@@ -162,7 +210,12 @@ def attn_bwd(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp: Tensor,
     """-> d_hp [num_src, Dp], d_att_src, d_att_dst, d_bias, d_a_dst (None unless deferred)."""
     lib, dev = _lib.lib(), hp.device
     with torch.cuda.device(dev):
-        a = cfg.c_args(layout.num_dst, in_features, hp, a_dst, att_src, att_dst, bias)
+        a = cfg.c_args(layout.num_dst, in_features, hp, a_dst, att_src, att_dst, bias, layout.num_nodes,
+                       layout.num_edges)
+        hc = cfg.heads * cfg.channels
+        _expect(out, (layout.num_dst, hc), torch.float32, "out", dev)
+        _expect(lse, (layout.num_dst, cfg.heads), torch.float32, "lse", dev)
+        _expect(grad_out, (layout.num_dst, hc), torch.float32, "grad_out", dev)
         d_hp = torch.empty(layout.num_nodes, hp.size(1), dtype=torch.float32, device=dev)
         d_as = torch.empty_like(att_src)
         d_ad = torch.empty_like(att_dst)
@@ -189,7 +242,7 @@ def attn_fwd_partial(layout: GraphLayout, cfg: AttnConfig, in_features: int, hp_
     if hp_chunk.size(0) != layout.num_nodes:
         raise ValueError(f"chunk table has {hp_chunk.size(0)} rows, its layout {layout.num_nodes} sources")
     with torch.cuda.device(dev):
-        a = cfg.c_args(n, in_features, hp_chunk, a_dst, att_src, None, None)
+        a = cfg.c_args(n, in_features, hp_chunk, a_dst, att_src, None, None, layout.num_nodes, layout.num_edges)
         dp = cfg.heads * padded_channels(cfg.channels)
         m = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev)
         s = torch.empty(n, cfg.heads, dtype=torch.float32, device=dev)
@@ -208,6 +261,13 @@ def attn_fwd_combine(parts, cfg: AttnConfig, bias: Optional[Tensor], need_lse: b
     if not 1 <= len(parts) <= _lib.MAX_PARTS:
         raise ValueError(f"{len(parts)} chunks: between 1 and {_lib.MAX_PARTS}")
     dev, n = parts[0][0].device, parts[0][0].size(0)
+    dp = cfg.heads * padded_channels(cfg.channels)
+    for m, s, acc in parts:
+        _expect(m, (n, cfg.heads), torch.float32, "partial m", dev)
+        _expect(s, (n, cfg.heads), torch.float32, "partial s", dev)
+        _expect(acc, (n, dp), torch.float32, "partial acc", dev)
+    if bias is not None:
+        _expect(bias.view(-1), (cfg.heads * cfg.channels,), torch.float32, "bias", dev)
     with torch.cuda.device(dev):
         arr = (_lib.AttnPartial * len(parts))(*[
             _lib.AttnPartial(m.data_ptr(), s.data_ptr(), acc.data_ptr()) for m, s, acc in parts])
@@ -234,6 +294,14 @@ class ChunkedBackward:
         self.grad_out = grad_out
         self.n = a_dst.size(0)
         self.first = True
+        hc = cfg.heads * cfg.channels
+        _expect(a_dst, (self.n, cfg.heads), torch.float32, "a_dst", self.dev)
+        _expect(out, (self.n, hc), torch.float32, "out", self.dev)
+        _expect(lse, (self.n, cfg.heads), torch.float32, "lse", self.dev)
+        _expect(grad_out, (self.n, hc), torch.float32, "grad_out", self.dev)
+        for name, t in (("att_src", att_src), ("att_dst", att_dst), ("bias", bias)):
+            if t is not None:
+                _expect(t.view(-1), (hc,), torch.float32, name, self.dev)
         with torch.cuda.device(self.dev):
             shape = _lib.Shape(self.n, in_features, cfg.heads, cfg.channels)
             nbytes = self.lib.gatmi_attn_bwd_node_workspace_bytes(C.byref(shape), self.k, int(bool(cfg.feat_bf16)))
@@ -248,8 +316,15 @@ class ChunkedBackward:
                                                      self.node_ws.numel(), _stream(self.dev)),
                        "gatmi_attn_bwd_begin")
 
-    def _args(self, hp, cfg=None):
+    def _args(self, hp, cfg=None, rows=None, num_edges=None):
         cfg = cfg or self.cfg
+        if hp is not None:
+            _expect(hp, (rows, cfg.heads * padded_channels(cfg.channels)),
+                    torch.bfloat16 if cfg.feat_bf16 else torch.float32, "feature table", self.dev)
+        if cfg.mask_mode == _lib.MASK_BYTES and num_edges is not None:   # begin / end read no mask
+            if cfg.mask is None:
+                raise ValueError("mask_mode BYTES needs the piece's mask")
+            _expect(cfg.mask, (num_edges, cfg.heads), torch.uint8, "dropout mask", self.dev)
         a = _lib.Attn()
         a.shape = _lib.Shape(self.n, self.f, cfg.heads, cfg.channels)
         a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
@@ -273,7 +348,7 @@ class ChunkedBackward:
             if (d_hp.shape != (layout.num_nodes, dp) or d_hp.dtype != torch.float32
                     or not d_hp.is_contiguous()):
                 raise ValueError("d_hp_out must be a contiguous float32 [chunk rows, Dp] tensor")
-            a = self._args(hp_chunk, cfg_k)
+            a = self._args(hp_chunk, cfg_k, layout.num_nodes, layout.num_edges)
             ws = _ws(self.lib.gatmi_attn_bwd_chunk_workspace_bytes(layout.ref, C.byref(a.shape)), self.dev)
             _lib.check(self.lib.gatmi_attn_bwd_chunk(
                 layout.ref, C.byref(a), int(k), self.k, int(not self.first), self.grad_out.data_ptr(),
@@ -287,7 +362,7 @@ class ChunkedBackward:
         with torch.cuda.device(self.dev):
             if self.first:                        # no chunk ran (no edges at all)
                 self.d_a_dst.zero_()
-            a = self._args(hp_own)
+            a = self._args(hp_own, None, self.n)
             d_as = torch.empty_like(self.att_src)
             d_ad = torch.empty_like(self.att_dst)
             d_b = torch.empty_like(self.bias) if self.bias is not None else None
@@ -308,6 +383,9 @@ def add_dst_term(d_hp: Tensor, d_a_dst: Tensor, att_dst: Tensor, heads: int, cha
     """d_hp[i,h,:] += d_a_dst[i,h] * att_dst[h,:] in place (rows of one shard)."""
     lib, dev = _lib.lib(), d_hp.device
     shape = _lib.Shape(d_hp.size(0), 1, heads, channels)
+    _expect(d_hp, (d_hp.size(0), heads * padded_channels(channels)), torch.float32, "d_hp", dev)
+    _expect(d_a_dst, (d_hp.size(0), heads), torch.float32, "d_a_dst", dev)
+    _expect(att_dst.view(-1), (heads * channels,), torch.float32, "att_dst", dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gatmi_add_dst_term(C.byref(shape), d_hp.data_ptr(), d_a_dst.data_ptr(),
                                           att_dst.data_ptr(), _stream(dev)), "gatmi_add_dst_term")
@@ -355,6 +433,8 @@ def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, head
     fs = int(lib.gatmi_inagg_xs_floats(C.byref(shape)))
     if fs == 0:
         raise RuntimeError(f"input-side aggregation does not cover F={f} H={heads}")
+    _project_operands(x, weight, att_dst, heads, channels)
+    _expect(att_src.view(-1), (heads * channels,), torch.float32, "att_src", dev)
     with torch.cuda.device(dev):
         xs = torch.empty(n, fs, dtype=torch.float32, device=dev)
         a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
@@ -383,6 +463,7 @@ def inagg_table16(xs: Tensor, in_features: int, heads: int, channels: int) -> Te
         raise RuntimeError(f"bf16 source rows do not cover F={in_features} H={heads}")
     if int(lib.gatmi_inagg_xs_floats(C.byref(shape))) != xs.size(1):
         raise ValueError("xs row width does not match this layer")
+    _expect(xs, tuple(xs.shape), torch.float32, "xs", dev)
     with torch.cuda.device(dev):
         xs16 = torch.empty(xs.size(0), row // 2, dtype=torch.bfloat16, device=dev)
         _lib.check(lib.gatmi_inagg_table16(C.byref(shape), xs.data_ptr(), xs16.data_ptr(), _stream(dev)),
@@ -392,6 +473,13 @@ def inagg_table16(xs: Tensor, in_features: int, heads: int, channels: int) -> Te
 
 def _inagg_args(cfg: AttnConfig, num_dst, in_features, xs, a_dst, weight, att_src, att_dst, bias,
                 xs16=None):
+    dev, hc = xs.device, cfg.heads * cfg.channels
+    _expect(xs, tuple(xs.shape), torch.float32, "xs", dev)
+    _expect(a_dst, (num_dst, cfg.heads), torch.float32, "a_dst", dev)
+    _expect(weight, (hc, in_features), torch.float32, "weight", dev)
+    for name, t in (("att_src", att_src), ("att_dst", att_dst), ("bias", bias)):
+        if t is not None:
+            _expect(t.view(-1), (hc,), torch.float32, name, dev)
     a = _lib.InAgg()
     a.shape = _lib.Shape(num_dst, in_features, cfg.heads, cfg.channels)
     a.negative_slope, a.dropout_p = cfg.negative_slope, cfg.dropout
@@ -419,6 +507,8 @@ def inagg_fwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, w
         a = _inagg_args(cfg, n, weight.size(1), xs, a_dst, weight, att_src, att_dst, bias, xs16)
         if int(lib.gatmi_inagg_xs_floats(C.byref(a.shape))) != xs.size(1):
             raise ValueError("xs row width does not match this layer")
+        if cfg.mask_mode == _lib.MASK_BYTES:
+            _expect(cfg.mask, (layout.num_edges, cfg.heads), torch.uint8, "dropout mask", dev)
         zf = int(lib.gatmi_inagg_z_floats(C.byref(a.shape)))
         out = torch.empty(n, cfg.heads * cfg.channels, dtype=torch.float32, device=dev)
         z = torch.empty(n, zf, dtype=torch.float32, device=dev)
@@ -435,9 +525,19 @@ def inagg_bwd(layout: GraphLayout, cfg: AttnConfig, xs: Tensor, a_dst: Tensor, w
               grad_out: Tensor, xs16: Optional[Tensor] = None):
     """-> d_weight, d_att_src, d_att_dst, d_bias (partial sums on a destination partition)."""
     lib, dev = _lib.lib(), xs.device
+    if xs.size(0) != layout.num_nodes:
+        raise ValueError(f"xs has {xs.size(0)} rows, the graph {layout.num_nodes} sources")
     with torch.cuda.device(dev):
         a = _inagg_args(cfg, layout.num_dst, weight.size(1), xs, a_dst, weight, att_src, att_dst,
                         bias, xs16)
+        if int(lib.gatmi_inagg_xs_floats(C.byref(a.shape))) != xs.size(1):
+            raise ValueError("xs row width does not match this layer")
+        zf = int(lib.gatmi_inagg_z_floats(C.byref(a.shape)))
+        _expect(z, (layout.num_dst, zf), torch.float32, "z", dev)
+        _expect(lse, (layout.num_dst, cfg.heads), torch.float32, "lse", dev)
+        _expect(grad_out, (layout.num_dst, cfg.heads * cfg.channels), torch.float32, "grad_out", dev)
+        if cfg.mask_mode == _lib.MASK_BYTES:
+            _expect(cfg.mask, (layout.num_edges, cfg.heads), torch.uint8, "dropout mask", dev)
         d_w = torch.empty_like(weight)
         d_as = torch.empty_like(att_src)
         d_ad = torch.empty_like(att_dst)

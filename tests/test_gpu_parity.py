@@ -769,7 +769,7 @@ def test_partition_kernels_match_oracle(cuda, gname, sname, world, balance):
     cfg = ops.AttnConfig(h, c)
     xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
     asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
-    parts = [make_partition(ei, n, world, r, balance) for r in range(world)]
+    parts = [make_partition(ei, n, world, r, balance, padding="pad") for r in range(world)]   # the tables below are padded by hand
     shards = []
     for p in parts:
         hp, a_dst = be.project_fwd(xd[p.lo:p.hi].contiguous(), wd, add_, cfg)
@@ -832,7 +832,7 @@ def _partition_input_aggregation(cuda, gname, sname, world, balance, rows16):
     cfg.stream = 1 + world % 2          # streaming forward for odd worlds, registers for even
     xd, wd, bd, god = x.to(cuda), w.to(cuda), b.to(cuda), go.to(cuda)
     asd, add_ = a_s.to(cuda).view(-1), a_d.to(cuda).view(-1)
-    parts = [make_partition(ei, n, world, r, balance) for r in range(world)]
+    parts = [make_partition(ei, n, world, r, balance, padding="pad") for r in range(world)]   # the tables below are padded by hand
     packed = [be.inagg_pack(xd[p.lo:p.hi].contiguous(), wd, asd, add_, cfg) for p in parts]
     table = torch.cat([torch.cat([xs, xs.new_zeros(p.block - p.n_local, xs.size(1))])
                        for p, (xs, _) in zip(parts, packed)])

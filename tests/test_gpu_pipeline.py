@@ -75,7 +75,7 @@ def _piecewise_layer(cuda, ei, n, f, h, c, world, chunks, padding, p=0.0, mask=N
 CASES = [("multigraph", "conv1_h30", 2, 2, 0.0), ("star", "arxiv_h64", 3, 3, 0.0),
          ("hub_source", "three_heads", 2, 4, 0.4), ("knn", "cora_l2", 4, 2, 0.0),
          ("star", "hidden_8x32", 2, 4, 0.5), ("multigraph", "arxiv_h64", 3, 2, 0.3),
-         ("chain", "conv1_h30", 3, 4, 0.0)]
+         ("chain", "conv1_h30", 3, 4, 0.0), ("star", "arxiv_h64", 3, 1, 0.3)]
 
 
 @pytest.mark.parametrize("padding", ["pad", "exact"])

@@ -196,3 +196,35 @@ def test_evolutionary_generations_shard_over_ranks_and_agree():
     assert got[0][1] + got[1][1] == 10 + 15 + 15          # every configuration evaluated once, somewhere
     assert got[0][1] > 0 and got[1][1] > 0
     assert got[0][2:] == got[1][2:]
+
+
+def test_operand_checks_refuse_short_tensors_before_any_launch():
+    """ops._expect: the kernels index by the sizes the descriptors state, so a tensor shorter than
+    stated must be an exception on the host, never a launch (a d_h table cut to the first piece's
+    rows reached gatmi_project_bwd in a bench tool and faulted the card)."""
+    from gat_amd import ops
+    t = torch.zeros(5, 8)
+    with pytest.raises(ValueError, match="expected shape"):
+        ops._expect(t, (6, 8), torch.float32, "d_hp")
+    with pytest.raises(TypeError, match="expected torch.float32"):
+        ops._expect(t.double(), (5, 8), torch.float32, "d_hp")
+    with pytest.raises(ValueError, match="contiguous"):
+        ops._expect(torch.zeros(8, 5).t(), (5, 8), torch.float32, "d_hp")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops._expect(t, (5, 8), torch.float32, "d_hp")
+    ops._expect(None, (1,), torch.float32, "optional")          # absent optional operands pass
+    with pytest.raises(ValueError, match="d_hp: expected shape"):
+        ops.project_bwd(torch.zeros(10, 4).cuda() if torch.cuda.is_available() else _FakeCuda(10, 4),
+                        _FakeCuda(6, 4), _FakeCuda(5, 8), 2, 3, True)
+
+
+class _FakeCuda(torch.Tensor):
+    """A CPU tensor that says it is on the GPU: reaches the shape checks without a device."""
+
+    @staticmethod
+    def __new__(cls, *shape):
+        return torch.Tensor._make_subclass(cls, torch.zeros(*shape))
+
+    @property
+    def is_cuda(self):
+        return True
