@@ -123,6 +123,7 @@ int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight
                        const float *d_a_dst, const float *att_dst, float *d_weight, float *d_x,
                        void *ws, hipStream_t st);
 // the row-streaming d_W kernel of gemm_split3.hip with 3 (exact split) or 1 (bf16 rounding) pieces
+int rows_dw_groups(const gatmi_shape &s, int nblocks);   // slabs of `part` (Dp * F floats each) rows_dw needs
 int rows_dw(const gatmi_shape *s, const float *x, const float *d_hp, const float *d_a_dst,
             const float *att_p, float *d_weight, float *part, int nblocks, int pieces, hipStream_t st);
 

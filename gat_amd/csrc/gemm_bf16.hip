@@ -43,21 +43,23 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4v &a, const f32x4v &b) {
 // k < Kp = round_up(K, 16), zero padded.  transpose == 0: src[n * ld + k] (lin.weight as it is,
 // rows = output channels, head-padded through `C`/`Cp`); transpose == 1: src[k * ld + n] (the
 // same weight read the other way round, for d_x = d_h W: n = input feature, k = padded channel).
+// n0: first output column of this image (a column pass); row n is column n0 + n, Nn counts from n0.
 __global__ void weight_image_kernel(const float *src, int ld, int Nn, int K, int NnP, int Kp,
-                                    int transpose, int C, int Cp, uint16_t *img) {
+                                    int transpose, int C, int Cp, int n0, uint16_t *img) {
     const int total = NnP * (Kp / 2);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int n = i / (Kp / 2), k = (i % (Kp / 2)) * 2;
+        const int ng = n0 + n;
         float v[2];
         for (int u = 0; u < 2; ++u) {
             const int kk = k + u;
             float val = 0.f;
             if (!transpose) {                   // n = padded output channel, k = input feature
-                const int head = n / Cp, c = n % Cp;
+                const int head = ng / Cp, c = ng % Cp;
                 if (n < Nn && c < C && kk < K) val = src[(size_t)(head * C + c) * ld + kk];
             } else {                            // n = input feature, k = padded output channel
                 const int head = kk / Cp, c = kk % Cp;
-                if (n < Nn && kk < K && c < C) val = src[(size_t)(head * C + c) * ld + n];
+                if (n < Nn && kk < K && c < C) val = src[(size_t)(head * C + c) * ld + ng];
             }
             v[u] = val;
         }
@@ -72,13 +74,16 @@ __global__ void pad_att_kernel(const float *att, int H, int C, int Cp, float *at
 }
 
 constexpr int kKresThreads = 512;
+constexpr size_t kLdsBytes = 160 * 1024;
+constexpr int kBf16MaxCols = 320;     // 8 heads x 40 channels: the widest layer the reference searches
 constexpr int kKresPad = 8;          // bf16 elements of padding per image row (16 bytes)
 constexpr int kPF = 4;               // A fragments in flight per lane (k-steps ahead)
 
 // C[M, Nn] = (A + fix)[M, K] * img^T.   A: f32 row-major (lda, rows 16-byte aligned, K % 4 == 0).
 // OUT_BF16: C is a bf16 table with row stride ldc elements, all NnP columns written (the pad
 // columns are zero because the image's pad rows are); else f32, columns < Nn.
-// FIX: A[m][k] += da_dst[m * H + k / Cp] * att_p[k]  (Cp % 8 == 0).
+// FIX: A[m][k] += da_dst[m * H + k / Cp] * att_p[k]; Cp % 4 == 0, so each float4 of a fragment lies in
+// one head (the two of a fragment in two different ones when Cp % 8 == 4: widths 28 and 36).
 template <int NT, bool OUT_BF16, bool FIX>
 __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
     const float *__restrict__ A, int lda, const uint16_t *__restrict__ img, void *__restrict__ Cout,
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
         f32x4v ra[kPF][2];
-        float rd[kPF];
+        float rd[kPF][2];
         auto fetch = [&](int u, int s) {
             const int k = s * 16 + half * 8;
             // a step past K (Kp > K) reads clamped addresses; its values are zeroed below
@@ -125,7 +130,10 @@ __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
             const float *p = A + (size_t)row * lda + kc;
             ra[u][0] = *reinterpret_cast<const f32x4v *>(p);
             ra[u][1] = *reinterpret_cast<const f32x4v *>(p + 4);
-            if (FIX) rd[u] = da_dst[(size_t)row * H + min(k, K - 1) / Cp];
+            if (FIX) {
+                rd[u][0] = da_dst[(size_t)row * H + min(k, K - 1) / Cp];
+                rd[u][1] = da_dst[(size_t)row * H + min(k + 4, K - 1) / Cp];
+            }
         };
 #pragma unroll
         for (int u = 0; u < kPF; ++u) fetch(u, min(u, S - 1));
@@ -139,8 +147,8 @@ __global__ __launch_bounds__(kKresThreads, 1) void gemm_bf16_kres_kernel(
                     if (FIX) {
                         const f32x4v t0 = *reinterpret_cast<const f32x4v *>(attl + k);
                         const f32x4v t1 = *reinterpret_cast<const f32x4v *>(attl + k + 4);
-                        a0 += rd[u] * t0;
-                        a1 += rd[u] * t1;
+                        a0 += rd[u][0] * t0;
+                        a1 += rd[u][1] * t1;
                     }
                     if (k + 8 > K) {                          // the ragged last step of K % 16 != 0
 #pragma unroll
@@ -367,7 +375,7 @@ static int launch_kres_bf16(int NT, const float *A, int lda, const uint16_t *img
     const size_t lds = (size_t)NT * 32 * (Kp + kKresPad) * 2 + (FIX ? (size_t)Kp * 4 : 0) +
                        (a_dst_out ? (size_t)NT * 32 * 4 : 0);
     GATMI_REQUIRE(!a_dst_out || (OUT_BF16 && !FIX && Cp % 32 == 0 && att_p), "bf16 projection: fused a_dst");
-    GATMI_REQUIRE(lds <= 160 * 1024, "bf16 projection: %d x %d weights do not fit LDS", NT * 32, Kp);
+    GATMI_REQUIRE(lds <= kLdsBytes, "bf16 projection: %d x %d weights do not fit LDS", NT * 32, Kp);
     const long long tiles = (M + 31) / 32;
     const int per = kKresThreads / 64;
     long long blocks = (tiles + per - 1) / per;
@@ -418,11 +426,28 @@ static Bf16Geo bf16_geo(const gatmi_shape &s) {
     g.Fp32 = (s.in_features + 31) / 32 * 32;
     return g;
 }
+// Column passes of a K-resident product: the fewest equal groups of 32-column tiles such that a
+// group has at most 8 tiles (accumulator registers) and its image -- tiles * 32 rows of Kp + pad
+// bf16 -- fits LDS beside `extra` bytes.  0: no such split.
+static int kres_passes(int tiles, int Kp, size_t extra) {
+    for (int p = 1; p <= 4; ++p) {
+        const int per = (tiles + p - 1) / p;
+        if (per <= 8 && (size_t)per * 32 * (Kp + kKresPad) * 2 + extra <= kLdsBytes) return p;
+    }
+    return 0;
+}
 static int dw_blocks(long long n) {
     long long b = (n + 2047) / 2048;        // at least 2048 rows per block
     const int cus = device_cus();
     if (b > cus) b = cus;
     return (int)(b < 1 ? 1 : b);
+}
+
+// slabs of d_W partial sums the workspace holds: one per block of the first bf16 kernel, or one per
+// row group of the row-streaming kernel (more when few output pairs share many waves)
+static int bf16_dw_slabs(const gatmi_shape &s) {
+    const int b = dw_blocks(s.num_nodes), g = rows_dw_groups(s, b);
+    return b > g ? b : g;
 }
 
 }  // namespace gatmi
@@ -432,19 +457,20 @@ using namespace gatmi;
 extern "C" int gatmi_project_bf16_supported(const gatmi_shape *s) {
     if (!s || s->heads < 1 || s->channels < 1 || s->in_features < 1) return 0;
     const Bf16Geo g = bf16_geo(*s);
-    // operand rows 16-byte aligned and whole 8-element halves (F % 8 == 0), heads that do not
-    // straddle an 8-wide k group (Cp % 8 == 0), both weight images within LDS, <= 256 columns
-    if (s->in_features % 8 || g.Cp % 8 || g.DpP > 256 || g.Fp32 > 256) return 0;
-    const size_t fwd = (size_t)g.DpP * (g.Fp16 + kKresPad) * 2;
-    const size_t bwd = (size_t)g.Fp32 * (g.DpP + kKresPad) * 2 + (size_t)g.DpP * 4;
-    return fwd <= 160 * 1024 && bwd <= 160 * 1024 && gatmi_attn_bf16_supported(s);
+    // operand rows 16-byte aligned and whole 8-element halves (F % 8 == 0); heads on float4 boundaries
+    // (Cp % 4 == 0, always); table rows of whole 32-column tiles (Dp % 32 == 0); at most 320 columns
+    // either way, the weight image of a column pass within LDS.  hidden_dim 24 ... 40 at 8 heads
+    // (/root/reference/bayesian_search.py:121) are all covered.
+    if (s->in_features % 8 || g.DpP != g.Dp || g.DpP > kBf16MaxCols || g.Fp32 > kBf16MaxCols) return 0;
+    return kres_passes(g.DpP / 32, g.Fp16, 0) > 0 && kres_passes(g.Fp32 / 32, g.DpP, (size_t)g.DpP * 4) > 0 &&
+           gatmi_attn_bf16_supported(s);
 }
 
 extern "C" size_t gatmi_project_bf16_workspace_bytes(const gatmi_shape *s) {
     if (!s) return 0;
     const Bf16Geo g = bf16_geo(*s);
-    const size_t img = align_up((size_t)256 * 256 * 2);
-    const size_t part = align_up((size_t)dw_blocks(s->num_nodes) * g.DpP * g.Fp32 * 4);
+    const size_t img = align_up((size_t)kBf16MaxCols * kBf16MaxCols * 2);
+    const size_t part = align_up((size_t)bf16_dw_slabs(*s) * g.DpP * g.Fp32 * 4);
     return img + align_up((size_t)g.DpP * 4) + part + 256;
 }
 
@@ -460,15 +486,13 @@ extern "C" int gatmi_project_fwd_bf16(const gatmi_shape *s, const float *x, cons
     const Bf16Geo g = bf16_geo(*s);
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(ws);
-    uint16_t *img = cv.take<uint16_t>((size_t)256 * 256);
+    uint16_t *img = cv.take<uint16_t>((size_t)kBf16MaxCols * kBf16MaxCols);
     float *att_p = cv.take<float>(g.DpP);
     const long long N = s->num_nodes;
     if (N == 0) return GATMI_OK;
     const int F = s->in_features;
     {
         ProfScope ps("proj16_prep", st);
-        hipLaunchKernelGGL(weight_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
-                           g.Fp16, 0, s->channels, g.Cp, img);
         hipLaunchKernelGGL(pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst,
                            s->heads, s->channels, g.Cp, att_p);
         GATMI_HIP(hipGetLastError());
@@ -478,13 +502,23 @@ extern "C" int gatmi_project_fwd_bf16(const gatmi_shape *s, const float *x, cons
         ProfScope ps("proj16_fwd_gemm", st);
         // the table's row stride is Dp; the kernel writes DpP >= Dp columns only when DpP == Dp
         GATMI_REQUIRE(g.DpP == g.Dp, "bf16 projection: H * round_up(C, 4) = %d must be a multiple of 32", g.Dp);
-        // heads of whole 32-column tiles: a_dst leaves with the tiles (GATMI_ADST_FUSED=0: own kernel)
+        const int tiles = kres_nt(g.DpP);
+        // heads of whole 32-column tiles in one column pass: a_dst leaves with the tiles
+        // (GATMI_ADST_FUSED=0: own kernel)
         fused = g.Cp % 32 == 0 && option("GATMI_ADST_FUSED", 1) != 0 &&
-                (size_t)g.DpP * (g.Fp16 + kKresPad) * 2 + (size_t)g.DpP * 4 <= 160 * 1024;
-        if (int e = launch_kres_bf16<true, false>(kres_nt(g.DpP), x, F, img, hp16, g.Dp, N, g.Dp, F,
-                                                  g.Fp16, nullptr, fused ? att_p : nullptr, s->heads, g.Cp,
-                                                  st, fused ? a_dst : nullptr))
-            return e;
+                kres_passes(tiles, g.Fp16, (size_t)g.DpP * 4) == 1;
+        const int passes = fused ? 1 : kres_passes(tiles, g.Fp16, 0);
+        const int per = (tiles + passes - 1) / passes;
+        for (int t0 = 0; t0 < tiles; t0 += per) {       // passes share the image buffer (stream order)
+            const int nt = min(per, tiles - t0), n0 = t0 * 32;
+            hipLaunchKernelGGL(weight_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp - n0, F,
+                               nt * 32, g.Fp16, 0, s->channels, g.Cp, n0, img);
+            GATMI_HIP(hipGetLastError());
+            if (int e = launch_kres_bf16<true, false>(nt, x, F, img, static_cast<uint16_t *>(hp16) + n0, g.Dp, N,
+                                                      nt * 32, F, g.Fp16, nullptr, fused ? att_p : nullptr,
+                                                      s->heads, g.Cp, st, fused ? a_dst : nullptr))
+                return e;
+        }
     }
     if (!fused) {
         ProfScope ps("proj16_row_dots", st);
@@ -513,38 +547,43 @@ extern "C" int gatmi_project_bwd_bf16(const gatmi_shape *s, const float *x, cons
     const Bf16Geo g = bf16_geo(*s);
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(ws);
-    uint16_t *img = cv.take<uint16_t>((size_t)256 * 256);
+    uint16_t *img = cv.take<uint16_t>((size_t)kBf16MaxCols * kBf16MaxCols);
     float *att_p = cv.take<float>(g.DpP);
     const long long N = s->num_nodes;
     const int F = s->in_features, H = s->heads;
     const int nblocks = dw_blocks(N);
-    float *part = cv.take<float>((size_t)nblocks * g.DpP * g.Fp32);
+    float *part = cv.take<float>((size_t)bf16_dw_slabs(*s) * g.DpP * g.Fp32);
     GATMI_REQUIRE(g.DpP == g.Dp, "bf16 projection: H * round_up(C, 4) = %d must be a multiple of 32", g.Dp);
     if (N == 0) {
         GATMI_HIP(hipMemsetAsync(d_weight, 0, (size_t)H * s->channels * F * 4, st));
         return GATMI_OK;
     }
-    {
+    if (d_a_dst) {
         ProfScope ps("proj16_prep", st);
-        if (d_x)
-            hipLaunchKernelGGL(weight_image_kernel, dim3(64), dim3(256), 0, st, weight, F, F, g.Dp,
-                               g.Fp32, g.DpP, 1, s->channels, g.Cp, img);
-        if (d_a_dst)
-            hipLaunchKernelGGL(pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst, H,
-                               s->channels, g.Cp, att_p);
+        hipLaunchKernelGGL(pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst, H,
+                           s->channels, g.Cp, att_p);
         GATMI_HIP(hipGetLastError());
     }
     if (d_x) {
         ProfScope ps("proj16_bwd_x_gemm", st);
-        const int NT = g.Fp32 / 32;
-        int e;
-        if (d_a_dst)
-            e = launch_kres_bf16<false, true>(NT, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.DpP, d_a_dst,
-                                              att_p, H, g.Cp, st);
-        else
-            e = launch_kres_bf16<false, false>(NT, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.DpP, nullptr,
-                                               nullptr, H, g.Cp, st);
-        if (e) return e;
+        const int tiles = g.Fp32 / 32;
+        const int passes = kres_passes(tiles, g.DpP, d_a_dst ? (size_t)g.DpP * 4 : 0);
+        const int per = (tiles + passes - 1) / passes;
+        for (int t0 = 0; t0 < tiles; t0 += per) {
+            const int nt = min(per, tiles - t0), n0 = t0 * 32;
+            hipLaunchKernelGGL(weight_image_kernel, dim3(64), dim3(256), 0, st, weight, F, F - n0, g.Dp,
+                               nt * 32, g.DpP, 1, s->channels, g.Cp, n0, img);
+            GATMI_HIP(hipGetLastError());
+            const int nn = min(F - n0, nt * 32);
+            int e;
+            if (d_a_dst)
+                e = launch_kres_bf16<false, true>(nt, d_hp, g.Dp, img, d_x + n0, F, N, nn, g.Dp, g.DpP, d_a_dst,
+                                                  att_p, H, g.Cp, st);
+            else
+                e = launch_kres_bf16<false, false>(nt, d_hp, g.Dp, img, d_x + n0, F, N, nn, g.Dp, g.DpP, nullptr,
+                                                   nullptr, H, g.Cp, st);
+            if (e) return e;
+        }
     }
     if (option("GATMI_DW16_ROWS", 1)) {
         // the row-streaming kernel of gemm_split3.hip with one piece per operand

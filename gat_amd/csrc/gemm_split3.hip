@@ -47,21 +47,24 @@ __device__ __forceinline__ uint32_t cut_pair(float &a, float &b) {
 // (Nn, 32), chunks = Kp / 32).  transpose == 0: src[n * ld + k], rows = output channels in the
 // head-padded layout through C / Cp (forward: n = padded channel, k = input feature);
 // transpose == 1: src[k * ld + n] (d_x = d_h W: n = input feature, k = padded channel).
+// n0: first output column of this image (a column pass of a product wider than 256 columns);
+// row n of the image is column n0 + n, Nn counts the columns from n0 on.
 __global__ void split3_image_kernel(const float *src, int ld, int Nn, int K, int NnP, int Kp,
-                                    int transpose, int C, int Cp, uint16_t *img) {
+                                    int transpose, int C, int Cp, int n0, uint16_t *img) {
     const int total = NnP * (Kp / 2);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int n = i / (Kp / 2), k = (i % (Kp / 2)) * 2;
+        const int ng = n0 + n;
         float v[2];
         for (int u = 0; u < 2; ++u) {
             const int kk = k + u;
             float val = 0.f;
             if (!transpose) {
-                const int head = n / Cp, c = n % Cp;
+                const int head = ng / Cp, c = ng % Cp;
                 if (n < Nn && c < C && kk < K) val = src[(size_t)(head * C + c) * ld + kk];
             } else {
                 const int head = kk / Cp, c = kk % Cp;
-                if (n < Nn && kk < K && c < C) val = src[(size_t)(head * C + c) * ld + n];
+                if (n < Nn && kk < K && c < C) val = src[(size_t)(head * C + c) * ld + ng];
             }
             v[u] = val;
         }
@@ -80,16 +83,19 @@ __global__ void split3_pad_att_kernel(const float *att, int H, int C, int Cp, fl
 }
 
 // C[M, Nn] (f32, row stride ldc, columns < Nn) = (A + fix)[M, K] * W^T from the chunked image.
-// A: f32 row-major (lda), K % 8 == 0; Kp = round_up(K, 32): the image is zero past K, so whatever
-// finite values the A stream picks up there -- the head of the next row -- multiply zeros.
-// FIX: A[m][k] += da_dst[m * H + k / Cp] * att_p[k]  (Cp % 8 == 0; head_magic = 65536 / (Cp / 8) + 1).
+// A: f32 row-major (lda), K % 8 == 0; Kp = round_up(K, 32): fragments that lie past K -- the A stream
+// picks up the head of the next row there -- are set to zero before they are cut (the image is zero
+// past K as well, but Inf or NaN in row m + 1 times zero would be NaN in row m).
+// FIX: A[m][k] += da_dst[m * H + k / Cp] * att_p[k].  HEAD4 == false: Cp % 8 == 0, a fragment of 8 k lies
+// in one head, head_magic = 65536 / (Cp / 8) + 1; HEAD4: Cp % 8 == 4 (28, 36: the reference's search
+// widths), the two float4 of a fragment may belong to two heads, head_magic = 65536 / (Cp / 4) + 1.
 // A block walks one contiguous chunk of `tiles_per_block` 32-row tiles, 8 at a time (wave w: tile
 // w of the group), addressed by 32-bit byte offsets from the chunk's first row and clamped to the
 // end of the matrix (the host keeps a chunk below 2 GiB).
 // ADST (forward, without FIX): a_dst[m][h] = sum over the head's columns of C[m][.] att_p[.] leaves with
 // the tile -- heads are whole column tiles (tph = Cp / 32 of them); the sums go through a butterfly
 // over the 32 lanes of a half, lane q of the half keeps row q's and stores it.
-template <int NTN, bool FIX, bool ADST>
+template <int NTN, bool FIX, bool ADST, bool HEAD4 = false>
 __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
     const float *__restrict__ A, int lda, const uint16_t *__restrict__ img, float *__restrict__ Cout,
     int ldc, long long M, int Nn, int K, int Kp, const float *__restrict__ da_dst,
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
     };
 
     f32x4v ra[2][2];
-    float rd[2];
+    float rd[2][2];
     // position q of this wave's A stream in steps from step 0 of its current tile (q < 2 S)
     auto fetch = [&](int u, int q) {
         const int sq = q >= S ? q - S : q;
@@ -150,9 +156,17 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
         ra[u][0] = *reinterpret_cast<const f32x4v *>(Ab + vo);
         ra[u][1] = *reinterpret_cast<const f32x4v *>(Ab + vo + 16);
         if (FIX) {
-            const unsigned head = ((unsigned)(2 * sq + half) * head_magic) >> 16;
-            const unsigned vd = min(d_tile + (q >= S ? tsd : 0u) + head * 4u, max_d);
-            rd[u] = *reinterpret_cast<const float *>(Db + vd);
+            const unsigned dt = d_tile + (q >= S ? tsd : 0u);
+            if (HEAD4) {
+                const unsigned k4 = (unsigned)(2 * sq + half) * 2u;      // the fragment's first float4
+                const unsigned h0 = (k4 * head_magic) >> 16, h1 = ((k4 + 1u) * head_magic) >> 16;
+                rd[u][0] = *reinterpret_cast<const float *>(Db + min(dt + h0 * 4u, max_d));
+                rd[u][1] = *reinterpret_cast<const float *>(Db + min(dt + h1 * 4u, max_d));
+            } else {
+                const unsigned head = ((unsigned)(2 * sq + half) * head_magic) >> 16;
+                rd[u][0] = *reinterpret_cast<const float *>(Db + min(dt + head * 4u, max_d));
+                rd[u][1] = rd[u][0];
+            }
         }
     };
 
@@ -180,10 +194,14 @@ __global__ __launch_bounds__(kGemmThreads, 1) void split3_gemm_kernel(
             for (int t = 0; t < 2; ++t) {
                 const int s = 2 * c + t;
                 f32x4v a0 = ra[t][0], a1 = ra[t][1];
+                const int k = s * 16 + half * 8;
                 if (FIX) {
-                    const int k = s * 16 + half * 8;
-                    a0 += rd[t] * *reinterpret_cast<const f32x4v *>(attl + k);
-                    a1 += rd[t] * *reinterpret_cast<const f32x4v *>(attl + k + 4);
+                    a0 += rd[t][0] * *reinterpret_cast<const f32x4v *>(attl + k);
+                    a1 += rd[t][1] * *reinterpret_cast<const f32x4v *>(attl + k + 4);
+                }
+                if (k >= K) {        // K % 32 != 0: this fragment is the head of the next row, not data
+                    a0 = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    a1 = a0;
                 }
                 fetch(t, s + 2);
                 float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -279,21 +297,30 @@ template <bool FIX, int NP /* pieces per operand: 3 = exact split, 1 = plain bf1
 __global__ __launch_bounds__(kDwThreads, 1) void split3_dw_kernel(
     const float *__restrict__ dh, int Dp, const float *__restrict__ x, int F,
     const float *__restrict__ da_dst, const float *__restrict__ att_p, int H, int Cp,
-    long long n_rows, long long rows_per_block, int ldp /* row stride of part: F */,
-    float *__restrict__ part /* [gridDim.x][Dp][ldp] */) {
+    long long n_rows, long long rows_per_block /* rows of a row group */, int n_groups,
+    int ldp /* row stride of part: F */, float *__restrict__ part /* [n_groups][Dp][ldp] */) {
     __shared__ __attribute__((aligned(16))) unsigned char park[kDwLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
-    const long long n_beg = min(n_rows, (long long)blockIdx.x * rows_per_block);
+    // The (channel group, feature group) pairs of 128 x 128 outputs are dealt over ALL waves of the
+    // grid: wave g = 4 blockIdx.x + wave takes pair g % npairs of row group g / npairs and streams
+    // that group's rows once.  (With the pairs looped inside a wave, a 288- or 320-wide layer -- nine
+    // pairs on four waves -- passed four times over its rows.)  The waves of a block sit on
+    // neighbouring pairs of the same rows: the shared operand rows are L2 hits.
+    const int ncg = (Dp + 127) / 128, nfg = (F + 127) / 128, npairs = ncg * nfg;
+    const int gid = blockIdx.x * (kDwThreads / 64) + wave;
+    const int rg = gid / npairs, pair = gid - rg * npairs;
+    const long long n_beg = min(n_rows, (long long)rg * rows_per_block);
     const long long n_end = min(n_rows, n_beg + rows_per_block);
     const long long n_full = n_beg + (n_end - n_beg) / 16 * 16;      // whole 16-node steps end here
-    float *dst = part + (size_t)blockIdx.x * Dp * ldp;
+    float *dst = part + (size_t)rg * Dp * ldp;
     constexpr int NPROD = NP == 3 ? 6 : 1;                            // MFMAs per (i, t) tile pair and step
     // operand register s (0..11: A piece p tile i = 4 p + i; 12..23: B), element jj of this lane:
     // dword [s][jj][lane] -- a wave's store of one element is 256 contiguous bytes
     unsigned *mine = reinterpret_cast<unsigned *>(park) + wave * (24 * 4 * 64) + lane;
-    for (int cg = wave & 1; cg * 128 < Dp; cg += 2)
-        for (int fg = wave >> 1; fg * 128 < F; fg += 2) {
+    if (rg < n_groups)
+        {
+            const int cg = pair / nfg, fg = pair - cg * nfg;
             const int c0 = cg * 128, f0 = fg * 128;
             const bool c_ok = c0 + 4 * r < Dp, f_ok = f0 + 4 * r < F;      // Dp % 4 == F % 4 == 0
             const int c = c_ok ? c0 + 4 * r : 0, fx = f_ok ? f0 + 4 * r : 0;
@@ -460,30 +487,47 @@ static int split_dw_blocks(long long n) {
     if (b > cus) b = cus;
     return (int)(b < 1 ? 1 : b);
 }
-constexpr size_t kSplitImgElems = (size_t)3 * 256 * 256;
+// Row groups of the d_W kernel for a grid of `nblocks` blocks: its 4 * nblocks waves are dealt
+// pair-major over the 128 x 128 output pairs, so there are 4 * nblocks / pairs groups of rows (each
+// at least one 16-node step long); `part` holds one [Dp][F] slab per group.
+int rows_dw_groups(const gatmi_shape &s, int nblocks) {
+    const SplitGeo g = split_geo(s);
+    const int npairs = ((g.Dp + 127) / 128) * ((s.in_features + 127) / 128);
+    long long groups = (long long)nblocks * (kDwThreads / 64) / npairs;
+    const long long most = ((long long)s.num_nodes + 15) / 16;
+    if (groups > most) groups = most;
+    return (int)(groups < 1 ? 1 : groups);
+}
 
-// Operand rows 16-byte aligned and whole 8-element fragments (F % 8 == 0), heads that do not
-// straddle a fragment (Cp % 8 == 0), at most 256 columns either way; tall enough for the streaming
-// kernels to pay (below, the tiled f32 kernels of project.hip stay).
+constexpr int kSplitMaxCols = 320;      // 8 heads x 40 channels: the widest layer the reference searches
+constexpr size_t kSplitImgElems = (size_t)3 * kSplitMaxCols * kSplitMaxCols;
+
+// Operand rows 16-byte aligned and whole 8-element fragments (F % 8 == 0); heads on float4 boundaries
+// (Cp % 4 == 0, always); at most 320 columns either way -- beyond 256 output columns the product runs
+// as two column passes (the accumulators of ten 32-column tiles do not fit beside the operands) --;
+// tall enough for the streaming kernels to pay (below, the tiled f32 kernels of project.hip stay).
+// Covers hidden_dim 24 ... 40 at 8 heads (/root/reference/bayesian_search.py:121,
+// evolutionary_computing_search.py:213) for the layers whose input is 8 * hidden wide.
 bool split3_covers(const gatmi_shape &s) {
     if (s.heads < 1 || s.channels < 1 || s.in_features < 1 || s.num_nodes < 4096) return false;
     const SplitGeo g = split_geo(s);
-    return s.in_features % 8 == 0 && g.Cp % 8 == 0 && g.DpP <= 256 && g.Fp32 <= 256;
+    return s.in_features % 8 == 0 && g.DpP <= kSplitMaxCols && g.Fp32 <= kSplitMaxCols;
 }
 
 size_t split3_workspace_bytes(const gatmi_shape &s) {
     if (!split3_covers(s)) return 0;
     const SplitGeo g = split_geo(s);
-    const size_t part = align_up((size_t)split_dw_blocks(s.num_nodes) * g.Dp * s.in_features * 4);
+    const size_t part = align_up((size_t)rows_dw_groups(s, split_dw_blocks(s.num_nodes)) * g.Dp * s.in_features * 4);
     return align_up(kSplitImgElems * 2) + align_up((size_t)g.DpP * 4) + part + 256;
 }
 
-template <bool FIX, bool ADST = false>
+template <bool FIX, bool ADST = false, bool HEAD4 = false>
 static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16_t *img, float *C, int ldc,
                               long long M, int Nn, int K, int Kp, const float *da_dst,
                               const float *att_p, int H, int Cp, hipStream_t st, float *a_dst_out = nullptr) {
-    GATMI_REQUIRE(Kp % kCk == 0 && K % 8 == 0 && K >= 8 && Cp % 8 == 0 && tiles_n >= 1 && tiles_n <= 8,
-                  "split projection: K = %d, Kp = %d, %d column tiles", K, Kp, tiles_n);
+    GATMI_REQUIRE(Kp % kCk == 0 && K % 8 == 0 && K >= 8 && Cp % 4 == 0 && (HEAD4 || !FIX || Cp % 8 == 0) &&
+                      tiles_n >= 1 && tiles_n <= 8,
+                  "split projection: K = %d, Kp = %d, Cp = %d, %d column tiles", K, Kp, Cp, tiles_n);
     const size_t lds = (size_t)2 * 3 * tiles_n * 32 * kRowB + (FIX ? (size_t)Kp * 4 : 0) +
                        (ADST ? (size_t)tiles_n * 32 * 4 : 0);
     GATMI_REQUIRE(!ADST || (Cp % 32 == 0 && a_dst_out && att_p), "split projection: a_dst needs whole-tile heads");
@@ -498,10 +542,10 @@ static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16
     long long blocks = (tiles + tpb - 1) / tpb;
     blocks = (blocks + 7) / 8 * 8;                             // the XCD-contiguous order
     const int dev = device_index();
-    const unsigned head_magic = 65536u / (unsigned)(Cp / 8) + 1u;
+    const unsigned head_magic = 65536u / (unsigned)(HEAD4 ? Cp / 4 : Cp / 8) + 1u;
 #define GATMI_SPLIT3_GEMM(NTV)                                                                       \
     case NTV: {                                                                                      \
-        auto kern = split3_gemm_kernel<NTV, FIX, ADST>;                                              \
+        auto kern = split3_gemm_kernel<NTV, FIX, ADST, HEAD4>;                                       \
         static size_t granted[kMaxDevices] = {};   /* the attribute is per kernel and per device */  \
         if (granted[dev] < lds) {                                                                    \
             GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
@@ -530,7 +574,10 @@ static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16
 
 // hp [N, Dp] f32 (head-padded) = x W^T; with att_dst and a_dst, and heads that are whole 32-column tiles
 // (split3_fwd_makes_a_dst), also a_dst [N, H] = <hp[n, h, :], att_dst[h, :]> from the GEMM's epilogue
-bool split3_fwd_makes_a_dst(const gatmi_shape &s) { return split_geo(s).Cp % 32 == 0; }
+bool split3_fwd_makes_a_dst(const gatmi_shape &s) {
+    const SplitGeo g = split_geo(s);
+    return g.Cp % 32 == 0 && g.DpP <= 256;          // one column pass
+}
 int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight, const float *att_dst,
                        float *hp, float *a_dst, void *ws, hipStream_t st) {
     const SplitGeo g = split_geo(*s);
@@ -538,20 +585,29 @@ int split3_project_fwd(const gatmi_shape *s, const float *x, const float *weight
     uint16_t *img = cv.take<uint16_t>(kSplitImgElems);
     float *att_p = cv.take<float>(g.DpP);
     const int F = s->in_features;
-    if (a_dst && att_dst && g.Cp % 32 == 0) {
+    const int tiles = g.DpP / 32;
+    if (a_dst && att_dst && g.Cp % 32 == 0 && tiles <= 8) {
         hipLaunchKernelGGL(split3_pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst,
                            s->heads, s->channels, g.Cp, att_p);
         hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
-                           g.Fk, 0, s->channels, g.Cp, img);
+                           g.Fk, 0, s->channels, g.Cp, 0, img);
         GATMI_HIP(hipGetLastError());
-        return launch_split3_gemm<false, true>(g.DpP / 32, x, F, img, hp, g.Dp, s->num_nodes, g.Dp, F, g.Fk,
+        return launch_split3_gemm<false, true>(tiles, x, F, img, hp, g.Dp, s->num_nodes, g.Dp, F, g.Fk,
                                                nullptr, att_p, s->heads, g.Cp, st, a_dst);
     }
-    hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp, F, g.DpP,
-                       g.Fk, 0, s->channels, g.Cp, img);
-    GATMI_HIP(hipGetLastError());
-    return launch_split3_gemm<false>(g.DpP / 32, x, F, img, hp, g.Dp, s->num_nodes, g.Dp, F, g.Fk,
-                                     nullptr, nullptr, s->heads, g.Cp, st);
+    // more than 8 column tiles: two passes over x, each against its own image (same buffer: the
+    // passes are ordered on the stream)
+    const int first = tiles <= 8 ? tiles : (tiles + 1) / 2;
+    for (int t0 = 0; t0 < tiles; t0 += first) {
+        const int nt = min(first, tiles - t0), n0 = t0 * 32;
+        hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, g.Dp - n0, F, nt * 32,
+                           g.Fk, 0, s->channels, g.Cp, n0, img);
+        GATMI_HIP(hipGetLastError());
+        if (int e = launch_split3_gemm<false>(nt, x, F, img, hp + n0, g.Dp, s->num_nodes, min(g.Dp - n0, nt * 32),
+                                              F, g.Fk, nullptr, nullptr, s->heads, g.Cp, st))
+            return e;
+    }
+    return GATMI_OK;
 }
 
 // d_weight [H*C, F] = (d_hp + d_a_dst att_dst)^T x and d_x [N, F] = (d_hp + d_a_dst att_dst) W; a
@@ -566,7 +622,7 @@ int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight
     const long long N = s->num_nodes;
     const int F = s->in_features, H = s->heads;
     const int nblocks = split_dw_blocks(N);
-    float *part = cv.take<float>((size_t)nblocks * g.Dp * F);
+    float *part = cv.take<float>((size_t)rows_dw_groups(*s, nblocks) * g.Dp * F);
     if (d_a_dst) {
         hipLaunchKernelGGL(split3_pad_att_kernel, dim3((g.Dp + 255) / 256), dim3(256), 0, st, att_dst,
                            H, s->channels, g.Cp, att_p);
@@ -574,17 +630,26 @@ int split3_project_bwd(const gatmi_shape *s, const float *x, const float *weight
     }
     if (d_x) {
         ProfScope ps("proj_bwd_x_gemm", st);
-        hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, F, g.Dp,
-                           g.Fp32, g.Dk, 1, s->channels, g.Cp, img);
-        GATMI_HIP(hipGetLastError());
-        int e;
-        if (d_a_dst)
-            e = launch_split3_gemm<true>(g.Fp32 / 32, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.Dk, d_a_dst,
-                                         att_p, H, g.Cp, st);
-        else
-            e = launch_split3_gemm<false>(g.Fp32 / 32, d_hp, g.Dp, img, d_x, F, N, F, g.Dp, g.Dk, nullptr,
-                                          nullptr, H, g.Cp, st);
-        if (e) return e;
+        const int tiles = g.Fp32 / 32;
+        const int first = tiles <= 8 ? tiles : (tiles + 1) / 2;
+        for (int t0 = 0; t0 < tiles; t0 += first) {
+            const int nt = min(first, tiles - t0), n0 = t0 * 32;
+            hipLaunchKernelGGL(split3_image_kernel, dim3(64), dim3(256), 0, st, weight, F, F - n0, g.Dp,
+                               nt * 32, g.Dk, 1, s->channels, g.Cp, n0, img);
+            GATMI_HIP(hipGetLastError());
+            const int nn = min(F - n0, nt * 32);
+            int e;
+            if (!d_a_dst)
+                e = launch_split3_gemm<false>(nt, d_hp, g.Dp, img, d_x + n0, F, N, nn, g.Dp, g.Dk, nullptr,
+                                              nullptr, H, g.Cp, st);
+            else if (g.Cp % 8 == 0)
+                e = launch_split3_gemm<true>(nt, d_hp, g.Dp, img, d_x + n0, F, N, nn, g.Dp, g.Dk, d_a_dst,
+                                             att_p, H, g.Cp, st);
+            else
+                e = launch_split3_gemm<true, false, true>(nt, d_hp, g.Dp, img, d_x + n0, F, N, nn, g.Dp, g.Dk,
+                                                          d_a_dst, att_p, H, g.Cp, st);
+            if (e) return e;
+        }
     }
     if (d_weight) {
         ProfScope ps("proj_bwd_w_gemm", st);
@@ -603,10 +668,13 @@ int rows_dw(const gatmi_shape *s, const float *x, const float *d_hp, const float
     const int F = s->in_features, H = s->heads;
     GATMI_REQUIRE(F % 4 == 0 && g.Dp % 4 == 0 && nblocks >= 1 && (pieces == 1 || pieces == 3),
                   "rows_dw: F = %d, Dp = %d, %d blocks, %d pieces", F, g.Dp, nblocks, pieces);
-    const long long rpb = ((N + nblocks - 1) / nblocks + 15) / 16 * 16;
+    const int groups = rows_dw_groups(*s, nblocks);
+    const int npairs = ((g.Dp + 127) / 128) * ((F + 127) / 128);
+    const long long rpb = ((N + groups - 1) / groups + 15) / 16 * 16;
+    const int grid = (int)(((long long)groups * npairs + kDwThreads / 64 - 1) / (kDwThreads / 64));
 #define GATMI_ROWS_DW(FIXV, NPV)                                                                      \
-    hipLaunchKernelGGL((split3_dw_kernel<FIXV, NPV>), dim3(nblocks), dim3(kDwThreads), 0, st, d_hp, g.Dp, \
-                       x, F, d_a_dst, att_p, H, g.Cp, N, rpb, F, part)
+    hipLaunchKernelGGL((split3_dw_kernel<FIXV, NPV>), dim3(grid), dim3(kDwThreads), 0, st, d_hp, g.Dp, \
+                       x, F, d_a_dst, att_p, H, g.Cp, N, rpb, groups, F, part)
     if (pieces == 3) {
         if (d_a_dst) GATMI_ROWS_DW(true, 3);
         else GATMI_ROWS_DW(false, 3);
@@ -617,7 +685,7 @@ int rows_dw(const gatmi_shape *s, const float *x, const float *d_hp, const float
 #undef GATMI_ROWS_DW
     GATMI_HIP(hipGetLastError());
     hipLaunchKernelGGL(split3_dw_final_kernel, dim3((F + 31) / 32, 16), dim3(256), 0, st, part,
-                       nblocks, F, H, s->channels, g.Cp, F, d_weight);
+                       groups, F, H, s->channels, g.Cp, F, d_weight);
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }

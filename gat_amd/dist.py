@@ -774,6 +774,14 @@ class _PartitionedInAggFn(torch.autograd.Function):
             hit = (owner is not None and owner() is x_local and cache.get("version") == x_local._version
                    and cache.get("world") == part.world
                    and cache.get("bounds") == (part.bounds, part.uneven))
+            # The two branches issue collectives of different sizes, so the ranks must agree on
+            # which one runs: a rank whose x was rebuilt (or whose eval / train alternation differs)
+            # would otherwise meet full-row gathers with logit-only ones -- a deadlock or a corrupt
+            # table under RCCL instead of an error.  One 4-byte MIN all-reduce decides for everyone.
+            if part.world > 1:
+                flag = torch.tensor([1 if hit else 0], dtype=torch.int32, device=x_local.device)
+                all_reduce_(flag, group, op=dist.ReduceOp.MIN)
+                hit = bool(int(flag.item()))
             if not hit:                       # first call for this x: replicate the rows once
                 cache["table"] = gather_rows(xs_local, part, group)
                 cache["owner"], cache["version"] = weakref.ref(x_local), x_local._version

@@ -177,7 +177,15 @@ class GAT(nn.Module):
             with torch.cuda.graph(graph):
                 out, loss = self._eager_step(kind, data, zero=False)
             ent = self._graphs[key] = dict(data=data, graph=graph, out=out, loss=loss)
+            if kind == "train":     # the gradient tensors THIS graph writes (they live in its pool)
+                ent["grads"] = [p.grad for p in self.parameters()]
         ent["graph"].replay()
+        if kind == "train":
+            # Every captured training graph fills its own gradient tensors.  An eager step or the
+            # capture of another train set in between re-binds p.grad elsewhere; the optimizer must
+            # read what this replay has just written, not the other graph's stale values.
+            for p, g in zip(self.parameters(), ent["grads"]):
+                p.grad = g
         return ent["out"], ent["loss"]
 
     def _eager_step(self, kind: str, data, zero: bool = True):

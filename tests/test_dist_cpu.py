@@ -216,6 +216,56 @@ def _worker(rank, world, port, n, gname, exchange, balance, q, chunks=1, padding
         dist.destroy_process_group()
 
 
+def _stale_rank_worker(rank, world, port, q):
+    """exchange "as": rank 1 alone passes a NEW x tensor at the second step.  Its cache misses, the
+    other ranks' caches hit -- the MIN all-reduce makes every rank take the full gather, and the
+    result is that of the new x everywhere (the branch must be decided collectively)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gat_amd.dist import PartitionedGATConv
+        torch.set_num_threads(1)
+        ei, n_ = cases.random_multigraph(n=40, e=240)
+        f, h, c = 6, 3, 5
+        x, w, a_s, a_d, b, go = [t.double() for t in cases.layer_inputs(n_, f, h, c)]
+        conv = PartitionedGATConv(f, c, heads=h, backend=OracleBackend(), exchange="as",
+                                  balance="nodes").double().eval()
+        part = conv.partition_for(ei, n_)
+        with torch.no_grad():
+            conv.lin.weight.copy_(w); conv.att_src.copy_(a_s); conv.att_dst.copy_(a_d); conv.bias.copy_(b)
+        xl = x[part.lo:part.hi].clone()
+        conv(xl, ei, n_)                                   # fills every rank's cache
+        x2 = x.clone()
+        x2[part.lo:part.hi] = x[part.lo:part.hi] * (2.0 if rank == 1 else 1.0)
+        x2_all = x.clone()
+        lo1 = (n_ + world - 1) // world
+        x2_all[lo1:2 * lo1] *= 2.0                          # what the whole x is after rank 1's change
+        if rank == 1:
+            xl = x2[part.lo:part.hi].clone()               # a new tensor object on this rank only
+        out = conv(xl, ei, n_)
+        ref_out, _ = O.gatconv_grads_autograd(x2_all, ei, w, a_s, a_d, b, h, c, go)
+        torch.testing.assert_close(out.detach(), ref_out[part.lo:part.hi], rtol=1e-9, atol=1e-10)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cache_hit_of_exchange_as_is_decided_by_all_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stale_rank_worker, args=(r, 3, 29681, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def _run(world, n, gname, exchange, port, balance="nodes", chunks=1, padding="auto"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -103,8 +103,13 @@ def test_attention_kernels_on_a_bf16_table(cuda, kind, n, f, h, c, p):
                          f32_out, f32_g)
 
 
+# the last five: the reference's search widths hidden_dim 28, 34, 36, 40 at 8 heads
+# (/root/reference/bayesian_search.py:121, evolutionary_computing_search.py:213: heads on float4 but not
+# 8-element boundaries, 288 and 320 columns in two column passes) and the 24-wide one
 @pytest.mark.parametrize("n,f,h,c", [(4099, 256, 4, 64), (3000, 240, 8, 32), (1000, 64, 8, 8 * 4), (5001, 24, 4, 40),
-                                     (33, 8, 8, 32), (2500, 136, 2, 128), (1, 16, 4, 64)])
+                                     (33, 8, 8, 32), (2500, 136, 2, 128), (1, 16, 4, 64),
+                                     (3001, 224, 8, 28), (2100, 272, 8, 34), (2049, 288, 8, 36),
+                                     (3100, 320, 8, 40), (1500, 192, 8, 24)])
 @pytest.mark.parametrize("dw_rows", [-1, 0])
 def test_bf16_projection_gemms(cuda, n, f, h, c, dw_rows):
     """gatmi_project_fwd_bf16 / gatmi_project_bwd_bf16 through the C ABI against f64 products of
@@ -127,25 +132,31 @@ def _bf16_projection_gemms(cuda, n, f, h, c):
     att = torch.randn(h * c, generator=g)
     r = lambda t: t.to(torch.bfloat16).double()
     xd, wd, ad = x.to(cuda), w.to(cuda), att.to(cuda)
+    cp = (c + 3) // 4 * 4           # head-padded rows: C = 34 lives in 36 columns per head
     hp16, a_dst = ops.project_fwd_bf16(xd, wd, ad, h, c)
-    assert hp16.dtype == torch.bfloat16 and tuple(hp16.shape) == (n, h * c)
+    assert hp16.dtype == torch.bfloat16 and tuple(hp16.shape) == (n, h * cp)
     href = r(x) @ r(w).t()
     # one bf16 rounding of an f32-accumulated sum: half an ulp = 2^-9 of the value, plus the sum's own noise
-    got = hp16.double().cpu()
+    padded = hp16.double().cpu().view(n, h, cp)
+    assert (padded[:, :, c:] == 0).all()
+    got = padded[:, :, :c].reshape(n, h * c)
     assert float(((got - href).abs() - href.abs() * 2.0 ** -8).max()) <= 1e-5 * float(href.abs().max())
     close(a_dst, (got.view(n, h, c) * att.double().view(1, h, c)).sum(-1).float(), "a_dst")
     dh = torch.randn(n, h * c, generator=g)
     da = torch.randn(n, h, generator=g)
+    dh_p = torch.zeros(n, h, cp)
+    dh_p[:, :, :c] = dh.view(n, h, c)
+    dh_p = dh_p.view(n, h * cp)
     for with_term in (False, True):
         full = dh.double() + (da.double().unsqueeze(-1) * att.double().view(1, h, c)).reshape(n, h * c) \
             if with_term else dh.double()
-        dw, dx = ops.project_bwd_bf16(xd, wd, dh.to(cuda), h, c, True,
+        dw, dx = ops.project_bwd_bf16(xd, wd, dh_p.to(cuda), h, c, True,
                                       da.to(cuda) if with_term else None, ad if with_term else None)
         fr = full.float().to(torch.bfloat16).double()             # the kernel rounds d_h + term, once
         close(dx, (fr @ r(w)).float(), "d_x" + (" + term" if with_term else ""))
         close(dw, (fr.t() @ r(x)).float(), "d_weight" + (" + term" if with_term else ""))
         assert rel_l2(dx, full @ w.double()) <= 1e-2 and rel_l2(dw, full.t() @ x.double()) <= 1e-2
-    dw, none = ops.project_bwd_bf16(xd, wd, dh.to(cuda), h, c, False)
+    dw, none = ops.project_bwd_bf16(xd, wd, dh_p.to(cuda), h, c, False)
     assert none is None
     close(dw, (r(dh).t() @ r(x)).float(), "d_weight (no d_x)")
 

@@ -153,3 +153,25 @@ def test_hipgraph_training_matches_eager_training(cuda, tmp_path, monkeypatch):
     m = model.train_model(tr, va)
     assert all(np.isfinite(m.train_loss)) and len(set(m.train_loss)) == 8
     assert min(m.val_loss) < 0.52
+
+
+def test_hipgraph_training_alternating_two_train_sets_matches_eager(cuda, tmp_path, monkeypatch):
+    """two captured training graphs hold two sets of gradient tensors; p.grad must point
+    at the set the replay has just filled, or optimizer.step() applies the other graph's stale
+    gradients.  Epochs alternate between two train sets; losses equal the eager run's bit for bit."""
+    from gat_amd.model import GAT
+    monkeypatch.chdir(tmp_path)
+    X, y = synthetic_traces(1200, 25, seed=8)
+    sets = [convert_to_graph(X[:500], y[:500]), convert_to_graph(X[500:1000], y[500:1000])]
+    curves = []
+    for hipgraph in (False, True):
+        torch.manual_seed(4)
+        model = GAT(torch.optim.AdamW, 25, 2, weight_decay=4.8e-4, dropout=0.0, hidden_dim=30, epochs=1,
+                    lr=0.02, patience=50, device=cuda, verbose=False, hipgraph=hipgraph)
+        losses = []
+        for epoch in range(8):           # a, b, a, b, ...: eager, eager, capture, capture, replay ...
+            losses.append(model.train_epoch(sets[epoch % 2])[0])
+        curves.append(losses)
+        if hipgraph:
+            assert sum(1 for k in model._graphs if k[0] == "train") == 2
+    assert curves[0] == curves[1], curves

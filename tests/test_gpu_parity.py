@@ -95,20 +95,71 @@ def test_graph_layout_large_random(cuda):
 # them (ragged K and column tiles, a single 8-wide head, 8 input features, rows % 32 != 0); `split`
 # = 0 sends the same shapes through the f32 MFMA kernels instead
 @pytest.mark.parametrize("split", [-1, 0])
+# ...; the last five are the reference's search widths hidden_dim 24 ... 40 at 8 heads
+# (/root/reference/bayesian_search.py:121): heads on float4 but not 8-element boundaries (28, 36, and 34
+# padded to 36), 288 and 320 columns = two column passes, K = 240 (hidden 30: K % 32 != 0)
 @pytest.mark.parametrize("n,f,h,c", [(300, 25, 8, 30), (1000, 1433, 8, 8), (257, 240, 1, 2),
                                      (129, 128, 4, 64), (5, 3, 3, 5), (700, 64, 1, 7),
                                      (5003, 256, 8, 32), (4100, 72, 4, 24), (8192, 64, 1, 8),
-                                     (4097, 8, 2, 40), (20000, 256, 4, 64)])
+                                     (4097, 8, 2, 40), (20000, 256, 4, 64),
+                                     (4500, 224, 8, 28), (4099, 272, 8, 34), (33000, 288, 8, 36),
+                                     (5001, 320, 8, 40), (4200, 240, 8, 30)])
 def test_projection_fwd_bwd(cuda, n, f, h, c, split):
     from gat_amd import _lib
     if split == 0 and n < 4096:
         pytest.skip("not a split-GEMM shape")
     lib = _lib.lib()
+    if n >= 4096 and f % 8 == 0:      # every search width is on the fast path
+        assert _split3_covers(lib, n, f, h, c)
     _lib.set_option("GATMI_SPLIT3", split)
     try:
         _projection_fwd_bwd(cuda, lib, n, f, h, c)
     finally:
         _lib.set_option("GATMI_SPLIT3", -1)
+
+
+def _split3_covers(lib, n, f, h, c):
+    """the split GEMMs take a shape (from 4096 rows on) exactly when the workspace query reserves
+    their region: the query jumps by the weight image (3 x 320 x 320 bf16 = 614 KB) + the d_W slabs
+    between 4095 and 4096 rows; one more split-K slab of the f32 kernels is at most Dp * F * 4 = 410 KB"""
+    from gat_amd import _lib
+    assert n >= 4096
+    big, small = _lib.Shape(4096, f, h, c), _lib.Shape(4095, f, h, c)
+    grow = lib.gatmi_project_workspace_bytes(C.byref(big)) - lib.gatmi_project_workspace_bytes(C.byref(small))
+    return grow > 3 * 320 * 320 * 2
+
+
+def test_search_widths_are_on_the_fast_paths(cuda):
+    """hidden_dim 24 ... 40 at 8 heads (/root/reference/bayesian_search.py:121, random_search.py:160,
+    evolutionary_computing_search.py:213): conv2 of every width is taken by the split GEMMs (f32) and
+    by the bf16 projection."""
+    from gat_amd import _lib, ops
+    lib = _lib.lib()
+    for hidden in (24, 28, 30, 32, 34, 36, 40):
+        assert _split3_covers(lib, 100000, 8 * hidden, 8, hidden), hidden
+        assert ops.project_bf16_supported(8 * hidden, 8, hidden), hidden
+
+
+def test_split_projection_keeps_rows_apart_when_a_neighbour_overflows(cuda):
+    """with K % 32 != 0 (hidden 30: K = 240) the A stream of row m runs into the head of
+    row m + 1; those fragments are zeroed before they are cut, so an Inf / NaN row does not leak
+    into its neighbours (Inf * 0 would be NaN)."""
+    from gat_amd import ops
+    n, f, h, c = 5000, 240, 8, 30
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, f, generator=g)
+    x[1234] = float("inf")
+    x[4000, 7] = float("nan")
+    w = torch.randn(h * c, f, generator=g) / f ** 0.5
+    att = torch.randn(h * c, generator=g)
+    hp, a_dst = ops.project_fwd(x.to(cuda), w.to(cuda), att.to(cuda), h, c)
+    bad = ~torch.isfinite(hp).all(dim=1).cpu()
+    assert bad.nonzero().view(-1).tolist() == [1234, 4000]
+    dh = torch.randn(n, hp.size(1), generator=g)
+    dh.view(n, h, 32)[:, :, 30:] = 0
+    dh[77] = float("inf")
+    _, dx = ops.project_bwd(x.to(cuda), w.to(cuda), dh.to(cuda), h, c, True)
+    assert (~torch.isfinite(dx).all(dim=1).cpu()).nonzero().view(-1).tolist() == [77]
 
 
 def _projection_fwd_bwd(cuda, lib, n, f, h, c):
