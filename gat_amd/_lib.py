@@ -127,6 +127,14 @@ SYMBOLS = {
     "gatmi_glue_bwd": (C.c_int, [C.POINTER(Glue), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
+    "gatmi_glue_stats": (C.c_int, [C.POINTER(Glue), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p]),
+    "gatmi_glue_apply": (C.c_int, [C.POINTER(Glue), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "gatmi_glue_bwd_sums": (C.c_int, [C.POINTER(Glue), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_glue_bwd_apply": (C.c_int, [C.POINTER(Glue), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gatmi_glue_mask": (C.c_int, [C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
                                   C.c_void_p]),
     "gatmi_tail_workspace_bytes": (C.c_size_t, []),

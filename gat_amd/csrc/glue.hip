@@ -125,12 +125,14 @@ __global__ __launch_bounds__(256) void glue_stats_kernel(const GlueArgs A) {
 // columns: 256 / kFinCols row groups each take every such partial row, fixed-order adds through LDS.
 __global__ __launch_bounds__(256) void glue_stats_finalize_kernel(
     const float *partial, int nblocks, long long rows, int cols, int nslot, float eps, float momentum,
-    float *save_mean, float *save_rstd, float *running_mean, float *running_var) {
+    float *save_mean, float *save_rstd, float *running_mean, float *running_var,
+    float *m2_out /* row partition: M2 = sum (e - mean)^2 of these rows instead of rstd; the caller
+                     combines (rows, mean, M2) over the ranks */) {
     __shared__ double red[256];
     constexpr int CG = kFinCols, RG = 256 / CG;   // columns per block, row groups
     const int c = blockIdx.x * CG + (threadIdx.x & (CG - 1)), rg = threadIdx.x / CG;
     const bool on = c < cols;
-    const long long per = (rows + nblocks - 1) / nblocks;
+    const long long per = nblocks > 0 ? (rows + nblocks - 1) / nblocks : 0;    // no partials: zero rows
     const int ld = 2 * nslot * 4;
     auto nb = [&](int b) -> double {
         const long long r0 = (long long)b * per, r1 = r0 + per < rows ? r0 + per : rows;
@@ -161,6 +163,10 @@ __global__ __launch_bounds__(256) void glue_stats_finalize_kernel(
         for (int q = 0; q < RG; ++q) m2 += red[threadIdx.x + q * CG];
         const double var = rows > 0 ? m2 / (double)rows : 0.0;
         save_mean[c] = (float)mean;
+        if (m2_out) {
+            m2_out[c] = (float)m2;
+            return;
+        }
         save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         if (running_var) {
@@ -371,7 +377,7 @@ extern "C" int gatmi_glue_fwd(const gatmi_glue *g, const float *x, float *y, flo
         hipLaunchKernelGGL(glue_stats_finalize_kernel, dim3((g->cols + kFinCols - 1) / kFinCols), dim3(256), 0, st,
                            A.partial, blocks,
                            (long long)g->rows, g->cols, A.nslot, g->eps, g->momentum, save_mean,
-                           save_rstd, g->running_mean, g->running_var);
+                           save_rstd, g->running_mean, g->running_var, nullptr);
     } else {
         hipLaunchKernelGGL(glue_eval_stats_kernel, dim3(cb), dim3(256), 0, st, g->running_mean,
                            g->running_var, g->cols, g->eps, save_mean, save_rstd);
@@ -438,6 +444,106 @@ extern "C" int gatmi_glue_mask(int64_t rows, int32_t cols, float dropout_p, uint
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(glue_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        mask, (long long)rows, cols, thr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+// ---- The same glue on a ROW PARTITION (a destination-partitioned network: SURVEY.md 8e, "BatchNorm
+// batch statistics need a cross-GPU all-reduce"): the two reductions and the two passes as calls of
+// their own, so that the caller can combine the per-rank statistics / sums in between.
+//   forward   gatmi_glue_stats (this rank's rows -> mean, M2 per column)  | caller: Chan's combination
+//             over the ranks -> mean, rstd of ALL rows (+ running statistics)  | gatmi_glue_apply
+//   backward  gatmi_glue_bwd_sums (this rank's sum g', sum g' xhat)  | caller: all-reduce  |
+//             gatmi_glue_bwd_apply (with the sums and the row count of all ranks)
+extern "C" int gatmi_glue_stats(const gatmi_glue *g, const float *x, float *mean, float *m2, void *ws,
+                                size_t ws_bytes, void *stream) {
+    if (int e = glue_check(g)) return e;
+    GATMI_REQUIRE((x || g->rows == 0) && mean && m2, "glue_stats: null argument");
+    if (ws_bytes < gatmi_glue_workspace_bytes(g->cols)) {
+        set_error("glue workspace too small: %zu < %zu", ws_bytes, gatmi_glue_workspace_bytes(g->cols));
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GlueArgs A;
+    glue_fill(A, g);
+    A.x = x;
+    A.partial = static_cast<float *>(ws);
+    const int blocks = glue_blocks(g->rows);
+    ProfScope ps("glue_stats", st);
+    // zero rows: the finaliser walks no partial (nblocks = 0) and writes mean = M2 = 0
+    if (g->rows > 0) hipLaunchKernelGGL(glue_stats_kernel, dim3(blocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(glue_stats_finalize_kernel, dim3((g->cols + kFinCols - 1) / kFinCols), dim3(256), 0, st,
+                       A.partial, g->rows > 0 ? blocks : 0, (long long)g->rows, g->cols, A.nslot, g->eps,
+                       g->momentum, mean, nullptr, nullptr, nullptr, m2);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_glue_apply(const gatmi_glue *g, const float *x, const float *mean, const float *rstd,
+                                float *y, void *stream) {
+    if (int e = glue_check(g)) return e;
+    GATMI_REQUIRE(mean && rstd && g->gamma && g->beta && ((x && y) || g->rows == 0), "glue_apply: null argument");
+    if (g->rows == 0) return GATMI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GlueArgs A;
+    glue_fill(A, g);
+    A.x = x;
+    A.y = y;
+    A.mean = mean;
+    A.rstd = rstd;
+    ProfScope ps("glue_apply_fwd", st);
+    hipLaunchKernelGGL(glue_apply_fwd_kernel, dim3(glue_blocks(g->rows)), dim3(256), 0, st, A);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_glue_bwd_sums(const gatmi_glue *g, const float *x, const float *grad_y,
+                                   const float *mean, const float *rstd, float *sums, void *ws,
+                                   size_t ws_bytes, void *stream) {
+    if (int e = glue_check(g)) return e;
+    GATMI_REQUIRE(mean && rstd && sums && ((x && grad_y) || g->rows == 0), "glue_bwd_sums: null argument");
+    if (ws_bytes < gatmi_glue_workspace_bytes(g->cols)) {
+        set_error("glue workspace too small: %zu < %zu", ws_bytes, gatmi_glue_workspace_bytes(g->cols));
+        return GATMI_ERR_WS;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GlueArgs A;
+    glue_fill(A, g);
+    A.x = x;
+    A.gy = grad_y;
+    A.mean = mean;
+    A.rstd = rstd;
+    A.partial = static_cast<float *>(ws);
+    const int blocks = glue_blocks(g->rows);
+    ProfScope ps("glue_reduce_bwd", st);
+    if (g->rows > 0) hipLaunchKernelGGL(glue_reduce_bwd_kernel, dim3(blocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(glue_sum_partials_kernel, dim3((g->cols + kFinCols - 1) / kFinCols, 2), dim3(256), 0, st,
+                       A.partial, g->rows > 0 ? blocks : 0, g->cols, A.nslot, sums, nullptr, nullptr);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+
+extern "C" int gatmi_glue_bwd_apply(const gatmi_glue *g, int64_t total_rows, const float *x,
+                                    const float *grad_y, const float *mean, const float *rstd,
+                                    const float *sums, float *grad_x, void *stream) {
+    if (int e = glue_check(g)) return e;
+    GATMI_REQUIRE(mean && rstd && sums && g->gamma && ((x && grad_y && grad_x) || g->rows == 0),
+                  "glue_bwd_apply: null argument");
+    GATMI_REQUIRE(total_rows >= g->rows, "glue_bwd_apply: %lld rows in all, %lld of them here",
+                  (long long)total_rows, (long long)g->rows);
+    if (g->rows == 0) return GATMI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GlueArgs A;
+    glue_fill(A, g);
+    A.inv_rows = total_rows > 0 ? 1.0f / (float)total_rows : 0.f;    // the batch is all ranks' rows
+    A.x = x;
+    A.gy = grad_y;
+    A.gx = grad_x;
+    A.mean = mean;
+    A.rstd = rstd;
+    A.dsum = sums;
+    ProfScope ps("glue_apply_bwd", st);
+    hipLaunchKernelGGL(glue_apply_bwd_kernel, dim3(glue_blocks(g->rows)), dim3(256), 0, st, A);
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }

@@ -991,49 +991,100 @@ def sync_elu_bn_dropout(x_local: Tensor, bn: nn.BatchNorm1d, p: float, training:
     return torch.nn.functional.dropout(y, p, training)
 
 
+class _GlueExchange:
+    """the two collectives gat_amd.glue.elu_bn_dropout_rows needs, on this module's group"""
+
+    def __init__(self, group):
+        self.group = group
+
+    def gather(self, vec: Tensor) -> Tensor:
+        world = dist.get_world_size(self.group)
+        return all_gather_rows(vec.view(1, -1).contiguous(), world, self.group)
+
+    def sum_(self, t: Tensor) -> Tensor:
+        return all_reduce_(t, self.group)
+
+
 class PartitionedGAT(nn.Module):
     """The reference's network (/root/reference/gat/model.py:26-31, 37-47) on one large graph
     split over the ranks by destination: rank r holds rows [lo, hi) of x and y.  The three
     layers are PartitionedGATConv (their parameter gradients come back all-reduced), the two
     BatchNorms use global batch statistics, the loss is the mean over all N nodes.  Every rank
     back-propagates its own rows' share of that mean; call `sync_grads()` before the optimizer
-    step (BatchNorm's weight and bias gradients are partial sums until then)."""
+    step (BatchNorm's weight and bias gradients are partial sums until then).
+
+    fused (default on the HIP backend): ELU -> BatchNorm -> dropout between the layers runs on the
+    fused kernels of glue.hip -- two passes forward, two backward, with the per-column statistics
+    (Chan's combination of every rank's rows / mean / M2) and the backward's two column sums
+    exchanged between the passes -- and log_softmax + nll_loss on tail.hip (`forward_loss`).
+    fused=False keeps the stock torch ops (what the CPU stand-in backend of the tests runs).
+    feature_dtype=torch.bfloat16: bf16 feature tables in the layers (see PartitionedGATConv)."""
 
     def __init__(self, num_features, num_classes, hidden_dim=16, dropout=0.7, backend=None, group=None,
-                 balance="edges"):
+                 balance="edges", feature_dtype=None, chunks=None, padding="auto", fused=None):
         super().__init__()
-        kw = dict(dropout=dropout, backend=backend, group=group, balance=balance)
+        kw = dict(dropout=dropout, backend=backend, group=group, balance=balance,
+                  feature_dtype=feature_dtype, chunks=chunks, padding=padding)
         self.conv1 = PartitionedGATConv(num_features, hidden_dim, heads=8, **kw)
         self.bn1 = nn.BatchNorm1d(hidden_dim * 8)
         self.conv2 = PartitionedGATConv(hidden_dim * 8, hidden_dim, heads=8, **kw)
         self.bn2 = nn.BatchNorm1d(hidden_dim * 8)
         self.conv3 = PartitionedGATConv(hidden_dim * 8, num_classes, heads=1, **kw)
         self.p, self.group = dropout, group
+        self.fused = isinstance(self.conv1.backend, HipBackend) if fused is None else bool(fused)
+        self._exchange = _GlueExchange(group)
         self._gens = {}
 
     def partition_for(self, edge_index: Tensor, num_nodes: int) -> Partition:
         return self.conv1.partition_for(edge_index, num_nodes)
 
+    def _generator(self, device) -> torch.Generator:
+        """A generator of this rank's own per device: ranks are seeded identically so that their
+        parameters agree, and torch's global generator would then hand every rank the same mask
+        pattern for its different rows."""
+        gen = self._gens.get(device)
+        if gen is None:
+            gen = torch.Generator(device=device)
+            gen.manual_seed(torch.initial_seed() + 7919 * (dist.get_rank(self.group) + 1))
+            self._gens[device] = gen
+        return gen
+
     def _drop(self, t: Tensor) -> Tensor:
-        """Feature dropout (model.py:31,39,42,45) drawn from a generator of this rank's own:
-        ranks are seeded identically so that their parameters agree, and torch's global
-        generator would then hand every rank the same mask pattern for its different rows."""
+        """Feature dropout (model.py:31,39,42,45) drawn from this rank's generator."""
         if not self.training or self.p <= 0.0:
             return t
-        gen = self._gens.get(t.device)
-        if gen is None:
-            gen = torch.Generator(device=t.device)
-            gen.manual_seed(torch.initial_seed() + 7919 * (dist.get_rank(self.group) + 1))
-            self._gens[t.device] = gen
-        keep = torch.rand(t.shape, generator=gen, device=t.device) >= self.p
+        keep = torch.rand(t.shape, generator=self._generator(t.device), device=t.device) >= self.p
         return t * keep.to(t.dtype) / (1.0 - self.p)
 
-    def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
+    def _glue(self, x: Tensor, bn: nn.BatchNorm1d, num_nodes: int) -> Tensor:
+        """dropout(bn(elu(x))) with the batch statistics of all N rows (model.py:40-42, 43-45)"""
+        if self.fused:
+            from .glue import elu_bn_dropout_rows
+            seed = None
+            if self.training and self.p > 0.0:      # a mask stream of this rank's own
+                seed = int(torch.empty((), dtype=torch.int64).random_(
+                    generator=self._generator(torch.device("cpu"))).item())
+            return elu_bn_dropout_rows(x, bn, self.p, self.training, num_nodes, self._exchange, seed)
+        return self._drop(sync_elu_bn_dropout(x, bn, 0.0, self.training, num_nodes, self.group))
+
+    def logits(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
         x = self.conv1(self._drop(x_local), edge_index, num_nodes)
-        x = sync_elu_bn_dropout(x, self.bn1, 0.0, self.training, num_nodes, self.group)
-        x = self.conv2(self._drop(x), edge_index, num_nodes)
-        x = sync_elu_bn_dropout(x, self.bn2, 0.0, self.training, num_nodes, self.group)
-        return torch.log_softmax(self.conv3(self._drop(x), edge_index, num_nodes), dim=1)
+        x = self.conv2(self._glue(x, self.bn1, num_nodes), edge_index, num_nodes)
+        return self.conv3(self._glue(x, self.bn2, num_nodes), edge_index, num_nodes)
+
+    def forward(self, x_local: Tensor, edge_index: Tensor, num_nodes: int) -> Tensor:
+        return torch.log_softmax(self.logits(x_local, edge_index, num_nodes), dim=1)
+
+    def forward_loss(self, x_local: Tensor, edge_index: Tensor, num_nodes: int, y_local: Tensor):
+        """(log-probabilities of this rank's rows, this rank's share of the loss): model.py:47 and :53
+        in one pass forward and one backward on the fused tail when `fused`."""
+        z = self.logits(x_local, edge_index, num_nodes)
+        if self.fused and z.size(0) > 0:
+            from .glue import log_softmax_nll
+            logp, mean_local = log_softmax_nll(z, y_local)       # mean over this rank's rows
+            return logp, mean_local * (z.size(0) / num_nodes)
+        logp = torch.log_softmax(z, dim=1)
+        return logp, self.loss_share(logp, y_local, num_nodes)
 
     def loss_share(self, logp_local: Tensor, y_local: Tensor, num_nodes: int) -> Tensor:
         """This rank's share of F.nll_loss(out, y) over all N nodes (model.py:53): the shares of

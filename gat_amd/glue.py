@@ -104,6 +104,99 @@ def elu_bn_dropout(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, seed
                          bn.momentum, p if training else 0.0, seed)
 
 
+class _RowPartitionGlueFn(torch.autograd.Function):
+    """dropout(bn(elu(x))) on this rank's rows of a row-partitioned batch: BatchNorm's statistics and
+    the backward's two sums are those of ALL ranks' rows (gatmi_glue_stats / _apply / _bwd_sums /
+    _bwd_apply with a collective in between).  `exchange` supplies the collectives:
+    exchange.gather(vec) -> [world, len(vec)] (every rank's vector), exchange.sum_(t) (in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps, momentum, p, seed, total_rows, exchange):
+        lib, dev = _lib.lib(), x.device
+        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        n, d = x.shape
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            y = torch.empty_like(x)
+            g = _desc(n, d, training, eps, momentum, p, seed, gamma, beta, rmean, rvar)
+            if training:
+                mean_l = torch.empty(d, dtype=torch.float32, device=dev)
+                m2_l = torch.empty(d, dtype=torch.float32, device=dev)
+                ws = _ws(d, dev)
+                _lib.check(lib.gatmi_glue_stats(C.byref(g), x.data_ptr(), mean_l.data_ptr(), m2_l.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), st), "gatmi_glue_stats")
+                # Chan's combination of the ranks' (rows, mean, M2), in float64, identically on every rank
+                mine = torch.cat([torch.tensor([float(n)], dtype=torch.float64, device=dev),
+                                  mean_l.double(), m2_l.double()])
+                allv = exchange.gather(mine)                       # [world, 1 + 2 d]
+                cnt, means, m2s = allv[:, :1], allv[:, 1:1 + d], allv[:, 1 + d:]
+                tot = float(total_rows)
+                mean64 = (cnt * means).sum(0) / tot
+                m2 = (m2s + cnt * (means - mean64) ** 2).sum(0)
+                var = m2 / tot
+                mean = mean64.float()
+                rstd = torch.rsqrt(var + eps).float()
+                with torch.no_grad():        # nn.BatchNorm1d's update: unbiased variance, momentum
+                    rmean.mul_(1 - momentum).add_(momentum * mean)
+                    rvar.mul_(1 - momentum).add_((momentum * m2 / max(tot - 1.0, 1.0)).float())
+            else:
+                mean = rmean.clone()
+                rstd = torch.rsqrt(rvar + eps)
+            _lib.check(lib.gatmi_glue_apply(C.byref(g), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            y.data_ptr(), st), "gatmi_glue_apply")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (training, eps, momentum, p, seed, total_rows, exchange)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, eps, momentum, p, seed, total_rows, exchange = ctx.cfg
+        lib, dev = _lib.lib(), x.device
+        n, d = x.shape
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            gy = grad_y.contiguous()
+            gx = torch.empty_like(x)
+            sums = torch.empty(2, d, dtype=torch.float32, device=dev)
+            ws = _ws(d, dev)
+            g = _desc(n, d, training, eps, momentum, p, seed, gamma, beta, mean, rstd)
+            _lib.check(lib.gatmi_glue_bwd_sums(C.byref(g), x.data_ptr(), gy.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                       "gatmi_glue_bwd_sums")
+            # this rank's share of d_beta / d_gamma goes to autograd (the caller all-reduces parameter
+            # gradients once, with the others); the apply pass needs the sums over all rows now
+            d_beta, d_gamma = sums[0].clone(), sums[1].clone()
+            if training:
+                exchange.sum_(sums)
+            _lib.check(lib.gatmi_glue_bwd_apply(C.byref(g), int(total_rows), x.data_ptr(), gy.data_ptr(),
+                                                mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
+                                                gx.data_ptr(), st), "gatmi_glue_bwd_apply")
+        return gx, d_gamma, d_beta, None, None, None, None, None, None, None, None, None
+
+
+def elu_bn_dropout_rows(x: Tensor, bn: nn.BatchNorm1d, p: float, training: bool, total_rows: int,
+                        exchange, seed=None) -> Tensor:
+    """elu_bn_dropout for one rank's rows of a row-partitioned batch of `total_rows` rows
+    (gat_amd.dist.PartitionedGAT): same module, same results as one process on all rows would get.
+    The gradients of bn.weight / bn.bias come back as this rank's partial sums."""
+    if not x.is_cuda:
+        raise RuntimeError("gat_amd.glue runs on the GPU only (no CPU fallback)")
+    if x.dim() != 2 or x.size(1) != bn.num_features or x.dtype != torch.float32:
+        raise ValueError(f"x must be float32 [n, {bn.num_features}], got {x.dtype} {tuple(x.shape)}")
+    if not bn.affine or not bn.track_running_stats or bn.momentum is None:
+        raise ValueError("elu_bn_dropout_rows covers nn.BatchNorm1d's defaults (affine, running statistics, momentum)")
+    if total_rows < x.size(0) or total_rows < 1:
+        raise ValueError(f"{x.size(0)} local rows of {total_rows} in all")
+    drop = training and p > 0.0
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop else 0
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _RowPartitionGlueFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps,
+                                     bn.momentum, p if training else 0.0, seed, int(total_rows), exchange)
+
+
 class _TailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):

@@ -388,6 +388,25 @@ int gatmi_glue_fwd(const gatmi_glue *g, const float *x, float *y, float *save_me
 int gatmi_glue_bwd(const gatmi_glue *g, const float *x, const float *grad_y,
                    const float *save_mean, const float *save_rstd, float *grad_x,
                    float *grad_gamma, float *grad_beta, void *ws, size_t ws_bytes, void *stream);
+/* The same glue on a ROW PARTITION (one rank's rows of a destination-partitioned network; SURVEY 8e:
+ * "BatchNorm batch statistics need a cross-GPU all-reduce of per-column sums for exact parity" --
+ * model.py:27,29,41,44 on all N rows).  The two reductions and the two passes are calls of their own
+ * and the caller combines between them; g->rows = this rank's rows (0 is allowed), dropout as above:
+ *   gatmi_glue_stats      -> mean [D], m2 [D] = sum (elu(x) - mean)^2 over THESE rows (caller: Chan's
+ *                            combination of (rows, mean, m2) over the ranks -> mean, rstd of all rows)
+ *   gatmi_glue_apply      y = dropout(gamma (elu(x) - mean) rstd + beta) with the combined statistics
+ *   gatmi_glue_bwd_sums   -> sums [2][D] = sum g', sum g' xhat over these rows (this rank's share of
+ *                            grad_beta, grad_gamma; caller: all-reduce)
+ *   gatmi_glue_bwd_apply  grad_x with the all-reduced sums and total_rows = the rows of all ranks. */
+int gatmi_glue_stats(const gatmi_glue *g, const float *x, float *mean, float *m2, void *ws,
+                     size_t ws_bytes, void *stream);
+int gatmi_glue_apply(const gatmi_glue *g, const float *x, const float *mean, const float *rstd, float *y,
+                     void *stream);
+int gatmi_glue_bwd_sums(const gatmi_glue *g, const float *x, const float *grad_y, const float *mean,
+                        const float *rstd, float *sums, void *ws, size_t ws_bytes, void *stream);
+int gatmi_glue_bwd_apply(const gatmi_glue *g, int64_t total_rows, const float *x, const float *grad_y,
+                         const float *mean, const float *rstd, const float *sums, float *grad_x,
+                         void *stream);
 /* The keep-mask of (seed, row, column), bytes [N, D] -- what nn.Dropout's Bernoulli draw is to
  * the reference; for inspection and tests. */
 int gatmi_glue_mask(int64_t rows, int32_t cols, float dropout_p, uint64_t seed, uint8_t *mask,

@@ -43,8 +43,8 @@ def main():
         model.train()
         eid = ei.to(dev)
         part = model.partition_for(eid, n)
-        logp = model(x[part.lo:part.hi].to(dev), eid, n)
-        share = model.loss_share(logp, y[part.lo:part.hi].to(dev), n)
+        assert model.fused          # ELU/BN/dropout on glue.hip, log_softmax + nll on tail.hip
+        logp, share = model.forward_loss(x[part.lo:part.hi].to(dev), eid, n, y[part.lo:part.hi].to(dev))
         share.backward()
         model.sync_grads()
         err = float((logp.detach().cpu() - ref_logp.detach()).abs().max())
@@ -57,6 +57,16 @@ def main():
         ok &= good
         print(f"{'ok' if good else 'FAILED'} PartitionedGAT over RCCL: logp err {err:.2e} loss err {lerr:.2e} "
               f"worst relative grad err {gerr:.2e}", flush=True)
+        # the same network in bf16 mode with dropout: one training step runs and stays finite
+        torch.manual_seed(7)
+        m16 = PartitionedGAT(25, 2, hidden_dim=32, dropout=0.3, feature_dtype=torch.bfloat16).to(dev).train()
+        lp16, sh16 = m16.forward_loss(x[part.lo:part.hi].to(dev), eid, n, y[part.lo:part.hi].to(dev))
+        sh16.backward()
+        m16.sync_grads()
+        good = bool(torch.isfinite(lp16).all()) and all(bool(torch.isfinite(p.grad).all()) for p in m16.parameters())
+        good &= 0.3 < float(m16.global_loss(sh16)) < 2.0
+        ok &= good
+        print(f"{'ok' if good else 'FAILED'} PartitionedGAT bf16 mode + dropout over RCCL: loss {float(sh16):.4f}", flush=True)
         # every exchange mode of one layer against the single-GPU layer
         bf = torch.bfloat16
         # the last four: exchange "h" in pieces (asynchronous all_gather_into_tensor / reduce_scatter_tensor

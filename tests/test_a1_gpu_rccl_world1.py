@@ -32,7 +32,7 @@ def test_partitioned_layer_and_network_over_rccl():
         # the process group never came up (no check ran): an environment matter, reported as a skip so
         # that `pytest -x` goes on to the parity tests
         pytest.skip("one-rank nccl group could not be created here: " + r.stderr[-400:])
-    assert r.returncode == 0 and len(lines) == 14 and all(ln.startswith("ok") for ln in lines), \
+    assert r.returncode == 0 and len(lines) == 15 and all(ln.startswith("ok") for ln in lines), \
         r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -29,7 +29,7 @@ def _curves(cuda, opt_cls, lr, wd):
     for _ in range(10):
         ref.train(); opt.zero_grad()
         loss = F.nll_loss(ref(tr.x, tr.edge_index), tr.y); loss.backward(); opt.step()
-        ref_train.append(float(loss))
+        ref_train.append(float(loss.detach()))
         ref.eval()
         with torch.no_grad():
             ref_val.append(float(F.nll_loss(ref(va.x, va.edge_index), va.y)))
