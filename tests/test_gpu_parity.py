@@ -667,10 +667,53 @@ def test_layer_error_vs_fp64_is_oracle_sized(cuda):
     o32, g32 = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
     out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs)
     def err(a, ref):
-        return float((a.double().cpu().view_as(ref) - ref).abs().max() / ref.abs().max())
+        return float((a.detach().double().cpu().view_as(ref) - ref).abs().max() / ref.abs().max())
     assert err(out, t64) <= 4 * err(o32, t64) + 1e-7
     for k in g64:
         assert err(g[k], g64[k]) <= 4 * err(g32[k], g64[k]) + 1e-7, k
+
+
+@pytest.mark.parametrize("path,gname,sname,p,seg",
+                         [("rows",) + c for c in LAYER_CASES] + [("inagg",) + c for c in INAGG_CASES])
+def test_every_case_is_as_close_to_fp64_as_the_fp32_oracle(cuda, path, gname, sname, p, seg):
+    """the element-wise 2e-3 that d_att_* shows against the fp32 oracle is fp32 on sums
+    of cancelling terms, not the kernels: on EVERY graph family / shape / dropout case of the two
+    layer tests the HIP result is at most 4x as far from the fp64 oracle as the fp32 oracle itself,
+    or within 3e-6 of the tensor's scale (a third of the bar: the oracle is sometimes lucky -- 4e-8 on
+    the star graph -- where another summation order costs a few epsilons, and the input-side path
+    sums d_att_dst in another association, (sum_i s_i x_i) W instead of sum_i s_i (x_i W): 2e-6 on the
+    star graph), for the output and every gradient.  d_att_* are measured against the size of one
+    summand where the exact answer is (nearly) zero.  Element-wise, over the elements >= 1e-3 of the
+    largest, the same rule with the absolute term seen from an element a thousand times smaller
+    (3e-3): no fp32 sum in another order determines those elements better.  What was measured is
+    printed with the session's report (tests/parity_log.py)."""
+    ei, n = cases.GRAPHS[gname]()
+    f, h, c = cases.SHAPES[sname]
+    inputs = cases.layer_inputs(n, f, h, c)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    kw = dict(dropout=p, mask=mask, training=p > 0)
+    o64, g64 = O.gatconv_grads_autograd(x.double(), ei, w.double(), a_s.double(), a_d.double(), b.double(),
+                                        h, c, go.double(), **kw)
+    o32, g32 = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, **kw)
+    out, g = run_layer(cuda, ei, n, f, h, c, p, mask, seg, inputs, inagg=path == "inagg")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+
+    def errs(a, ref, floor):
+        a, ref = a.detach().double().cpu().view_as(ref), ref.detach()
+        scale = max(float(ref.abs().max()), floor, 1e-30)
+        diff = (a - ref).abs()
+        big = ref.abs() >= 1e-3 * scale
+        return float(diff.max()) / scale, (float((diff[big] / ref.abs()[big]).max()) if bool(big.any()) else 0.0)
+
+    for k, got, r32, r64 in [("out", out, o32, o64)] + [("d_" + k, g[k], g32[k], g64[k]) for k in g]:
+        floor = summand if "att" in k else 0.0
+        e_hip, el_hip = errs(got, r64, floor)
+        e_32, el_32 = errs(r32, r64, floor)
+        parity_log.record_vs_fp64(k, e_hip, e_32, el_hip, el_32)
+        assert e_hip <= 4 * e_32 + 3e-6, (k, e_hip, e_32)
+        assert el_hip <= 4 * el_32 + 3e-3, (k, el_hip, el_32)
 
 
 def test_no_self_loops_and_no_bias_and_mean_heads(cuda):
