@@ -48,7 +48,7 @@ def test_full_size_constant_rows_give_constant_output(cuda, full, inagg):
     out = conv(x, ei)
     expect = (x[:1] @ conv.lin.weight.t()) + conv.bias
     err = float((out.detach() - expect.detach()).abs().max())
-    assert err <= 2e-5 * float(expect.abs().max()), err
+    assert err <= 2e-5 * float(expect.detach().abs().max()), err
 
 
 def test_full_size_paths_and_kernel_variants_agree(cuda, full):
