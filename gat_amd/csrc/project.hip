@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kres_kernel(const float *__restri
 // floats, at most 128) for the lifetime of the block, the contraction is unrolled over KC
 // steps, and all 160 KB of LDS are tile buffers: NBUF = 3-4 per wave, two or three in flight.
 // ---------------------------------------------------------------------------------
-template <int NT, int KC, bool SWZ, bool TAIL>
+template <int NT, int KC, bool SWZ, bool TAIL, bool DBUF = false>
 __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restrict__ A, int lda,
                                                            const float *__restrict__ B, int ldb,
                                                            int b_kmajor, float *__restrict__ C,
@@ -858,6 +858,110 @@ __global__ __launch_bounds__(256, 1) void gemm_kreg_kernel(const float *__restri
         if (t + b * tstride < ntiles) issue(t + b * tstride, b);
     int buf = 0;
     long long after = t < ntiles ? (ntiles - 1 - t) / tstride : 0;   // this wave's tiles after t
+    if constexpr (DBUF) {
+        // Two accumulator sets: the stores of tile t-1 are issued in slices BETWEEN the MFMA groups
+        // of tile t (a lone wave per SIMD issues in order: with one set, a tile's 52 stores and
+        // their address arithmetic sit between its last MFMA and the next tile's first).  Only the
+        // wave's last tile can be the matrix's partial one, and that one is flushed after the loop
+        // with the predicated form; every tile stored inside the loop is whole.
+        f32x16 accs[2][NT];
+        f32x4 accts[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        constexpr int kStores = NT * 16;
+        constexpr int kSlice = (kStores + KC - 1) / KC;
+        const unsigned ldcb = (unsigned)ldc * 4u;
+        auto store_one = [&](const f32x16(&pa)[NT], char *cb, int s_) {
+            const int nt = s_ / 16, r = s_ % 16;
+            const int cn = nt * 32 + l;
+            const unsigned lo = (unsigned)(4 * half) * ldcb + (unsigned)cn * 4u;
+            const unsigned dr = (r & 3) + 8 * (r >> 2);
+            if (cn < gb.n_store) *reinterpret_cast<float *>(cb + (size_t)(dr * ldcb) + lo) = pa[nt][r] + bv[nt];
+        };
+        auto store_tail = [&](const f32x4 &pt, long long row0) {
+            if constexpr (TAIL) {
+                const int cn = NT * 32 + (lane & 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float tot = pt[i] + __shfl_xor(pt[i], 32, 64);
+                    const long long row = row0 + 4 * (l >> 2) + i;
+                    if (half == 0 && cn < gb.n_store && row < M) C[(size_t)row * ldc + cn] = tot + bvt;
+                }
+            }
+        };
+        auto body = [&](f32x16(&acc)[NT], f32x4 &acct, const f32x16(&pa)[NT], const f32x4 &pt, bool have_prev,
+                        long long prev_row0) {
+            kres_wait_vm((int)(after < nbuf - 1 ? after : nbuf - 1) * ninstr);
+            const char *at = abuf + buf * tileb + (unsigned)l * rowb;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            acct = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto a_read = [&](int j) {
+                const int c = 2 * j + half;
+                const int cc = c < nf4 ? c : 0;
+                const unsigned addr = (unsigned)(uintptr_t)(
+                    (const __attribute__((address_space(3))) char *)(at + (SWZ ? (cc ^ (l & 15)) : cc) * 16));
+                f32x4 v;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+                return v;
+            };
+            char *pcb = reinterpret_cast<char *>(C + prev_row0 * ldc);     // wave-uniform
+            f32x4 a4 = a_read(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4));
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                f32x4 an = a_read(j + 1 < KC ? j + 1 : j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], breg[j][i][nt], acc[nt], 0, 0, 0);
+                if constexpr (TAIL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acct = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[i], btail[j][i], acct, 0, 0, 0);
+                }
+                if (have_prev) {                       // wave-uniform: a slice of tile t-1's stores
+#pragma unroll
+                    for (int s_ = j * kSlice; s_ < (j + 1) * kSlice && s_ < kStores; ++s_) store_one(pa, pcb, s_);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an));
+                a4 = an;
+                __builtin_amdgcn_sched_barrier(0);     // keep each slice between its MFMA groups
+            }
+            if (have_prev) store_tail(pt, prev_row0);
+            if (t + (long long)nbuf * tstride < ntiles) issue(t + (long long)nbuf * tstride, buf);
+            buf = buf + 1 < nbuf ? buf + 1 : 0;
+        };
+        bool have_prev = false;
+        long long prev_row0 = 0;
+        int par = 0;
+        for (; t < ntiles; t += tstride, --after) {
+            if (par == 0) body(accs[0], accts[0], accs[1], accts[1], have_prev, prev_row0);
+            else body(accs[1], accts[1], accs[0], accts[0], have_prev, prev_row0);
+            have_prev = true;
+            prev_row0 = t * 32;
+            par ^= 1;
+        }
+        if (have_prev) {                               // the wave's last tile (maybe the partial one)
+            const int cur = par ^ 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cn = nt * 32 + l;
+                if (cn < gb.n_store) {
+                    float *cp = C + (size_t)(prev_row0 + 4 * half) * ldc + cn;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const float v = cur == 0 ? accs[0][nt][r] : accs[1][nt][r];
+                        if (prev_row0 + 4 * half + dr < M) cp[(size_t)dr * ldc] = v + bv[nt];
+                    }
+                }
+            }
+            store_tail(cur == 0 ? accts[0] : accts[1], prev_row0);
+        }
+        return;
+    }
     for (; t < ntiles; t += tstride, --after) {
         kres_wait_vm((int)(after < nbuf - 1 ? after : nbuf - 1) * ninstr);
         const char *at = abuf + buf * tileb + (unsigned)l * rowb;
@@ -1002,8 +1106,11 @@ int device_cus() {
     return cus[di];
 }
 
-template <int NT, int KC, bool SWZ, bool TAIL = false>
+template <int NT, int KC, bool SWZ, bool TAIL = false, bool DBUF = false>
 static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
+    if constexpr (!DBUF && NT <= 3) {        // A/B: two accumulator sets (GATMI_KREG_DBUF)
+        if (option("GATMI_KREG_DBUF", 0) != 0) return kreg_launch<NT, KC, SWZ, TAIL, true>(d, nf4, st);
+    }
     const size_t tileb = (size_t)32 * nf4 * 16;
     int nbuf = (int)((160 * 1024) / (4 * tileb));
     nbuf = nbuf > 4 ? 4 : nbuf;
@@ -1011,7 +1118,7 @@ static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     static size_t dyn_cap[kMaxDevices] = {};   // granted per kernel and per device (see kres_launch)
     const int di = device_index();
     if (lds > dyn_cap[di]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kreg_kernel<NT, KC, SWZ, TAIL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kreg_kernel<NT, KC, SWZ, TAIL, DBUF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             dyn_cap[di] = lds;
     }
@@ -1020,7 +1127,7 @@ static void kreg_launch(const GemmDesc &d, int nf4, hipStream_t st) {
     if (bx > need) bx = need;
     if (bx < 1) bx = 1;
     GemmBatch gb{d.sA, d.sB, d.sC, d.sSplit, d.sBias, d.bias, 1, d.n_store, nullptr};
-    hipLaunchKernelGGL((gemm_kreg_kernel<NT, KC, SWZ, TAIL>), dim3((unsigned)bx, d.nbatch), dim3(256), lds, st,
+    hipLaunchKernelGGL((gemm_kreg_kernel<NT, KC, SWZ, TAIL, DBUF>), dim3((unsigned)bx, d.nbatch), dim3(256), lds, st,
                        d.A, d.lda, d.B, d.ldb, d.b_kmajor ? 1 : 0, d.C, d.ldc, d.M, d.Nn, d.K, nf4, nbuf, gb);
 }
 

@@ -565,6 +565,36 @@ def test_fallback_kernels_match_oracle(cuda, option):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("dbuf", [1, 0], ids=["two_accumulator_sets", "one_set"])
+@pytest.mark.parametrize("n,f,h,c", [(4099, 100, 4, 64), (4128, 100, 4, 64), (33, 100, 4, 64), (9000, 25, 8, 30),
+                                     (4101, 50, 2, 47), (70001, 100, 4, 64)])
+def test_register_gemm_with_two_accumulator_sets(cuda, n, f, h, c, dbuf):
+    """GATMI_KREG_DBUF: gemm_kreg_kernel stores tile t-1 between the MFMA groups of tile t.  Ragged
+    and whole last tiles, one tile only, waves with one tile and waves with many (70001 rows on a
+    256-block grid), the 4x4x1 tail columns: the same sums in the same order as with one set, so
+    the two settings agree bit for bit -- and both are held to the oracle."""
+    from gat_amd import _lib, synth
+    ei = synth.powerlaw_graph(n, 5 * n, min(300, n - 1), seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 7)
+    x, w, a_s, a_d, b, go = inputs
+    res = []
+    for v in (dbuf, 1 - dbuf):
+        _lib.set_option("GATMI_KREG_DBUF", v)
+        try:
+            res.append(run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs, inagg=True))
+        finally:
+            _lib.set_option("GATMI_KREG_DBUF", -1)
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    if n <= 10000:
+        ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+        summand = float(go.abs().max() * (x @ w.t()).abs().max())
+        close(res[0][0], ref_out, "out")
+        for k in res[0][1]:
+            close(res[0][1][k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 def test_input_aggregation_properties_at_scale(cuda):
     """products-sized table (beyond the Infinity Cache: the streaming kernel is what auto picks):
     identical rows in -> identical rows + bias out (the softmax weights of every destination sum
