@@ -2715,8 +2715,7 @@ static DwPlan dw_plan(int N, int H, int C, int F) {
     } else if (p.nt == 3) {
         p.nt = 4;
     }
-    // two blocks of four waves per CU (GATMI_DW_WAVES: A/B runs of the overlapped backward)
-    long long waves = (long long)device_cus() * option("GATMI_DW_WAVES", 8);
+    long long waves = (long long)device_cus() * 8;         // two blocks of four waves per CU
     int ns = (int)(waves / H);
     const int maxs = N / 256;                              // >= 128 row pairs per wave
     if (ns > maxs) ns = maxs;
@@ -2940,26 +2939,6 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
 }
 
 namespace {
-// GATMI_DW_OVERLAP: d_W = g^T Z depends on neither q nor the edge pass, so it can run beside them
-// on a stream of the library's own (one per device, created at first use; fork / join by events,
-// which a stream capture follows).  Calls that overlap on one device share it and serialise there.
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
-};
-SideStream *side_stream() {
-    static SideStream all[kMaxDevices];
-    SideStream &ss = all[device_index()];
-    if (!ss.tried) {
-        ss.tried = true;
-        if (hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
-            ss.stream = nullptr;
-    }
-    return ss.stream ? &ss : nullptr;
-}
 struct InBwdWs {
     float *q, *part_y, *dwsd, *slab, *gsum, *bdiag;
     int waves, nsplit;
@@ -3005,33 +2984,6 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     const InBwdWs w = carve_in_bwd(g, &a->shape, geo, ws);
     InArgs A;
     fill_in_args(A, g, a, geo);
-    // slab[split][h] = g[:, h, :]^T Z[:, h, :] over the split's rows
-    auto dw_gemm = [&](hipStream_t s2) -> int {
-        ProfScope ps("inagg_dw_gemm", s2);
-        GemmDesc d{};
-        d.a_kmajor = true; d.b_kmajor = true;
-        d.A = grad_out; d.lda = H * C; d.sA = C;
-        d.B = z; d.ldb = geo.HF; d.sB = geo.Fp;
-        d.C = w.slab; d.ldc = F; d.sC = (long long)C * F; d.sSplit = (long long)H * C * F;
-        d.M = C; d.Nn = F; d.K = N; d.n_store = F; d.nbatch = H; d.nsplit = w.nsplit;
-        d.bias = nullptr; d.sBias = 0;
-        d.fix = AFix{nullptr, nullptr, 1, 1};
-        d.asum = d_bias ? w.gsum : nullptr;   // [h][split][C]: d_bias rides on the staging of g
-        const DwPlan dp = dw_plan(N, H, C, F);
-        if (dp.stream) {
-            dw_stream(dp, grad_out, z, N, H, C, F, geo.Fp, w.slab, d_bias ? w.gsum : nullptr, s2);
-            GATMI_HIP(hipGetLastError());
-            return GATMI_OK;
-        }
-        return launch_gemm(d, s2);
-    };
-    SideStream *side = (N > 0 && option("GATMI_DW_OVERLAP", 0) != 0) ? side_stream() : nullptr;
-    if (side) {
-        GATMI_HIP(hipEventRecord(side->fork, st));
-        GATMI_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if (int e = dw_gemm(side->stream)) return e;
-        GATMI_HIP(hipEventRecord(side->join, side->stream));
-    }
     if (N > 0) {
         // q[:, h, :] = g[:, h, :] W_h   (padded columns written as zeros)
         ProfScope ps("inagg_q_gemm", st);
@@ -3069,12 +3021,10 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     A.zin = z;
     A.lsein = lse;
     A.part_y = w.part_y;
-    int grid = w.waves / 4;
     {
         ProfScope ps("inagg_bwd_edge", st);
         // every wave of the grid writes its partial row, also when it had no work item
-        const int cap = option("GATMI_BWD_BLOCKS", 0);          // A/B runs: a smaller grid
-        if (cap >= 8 && cap < grid) grid = cap / 8 * 8;
+        const int grid = w.waves / 4;
         if (A.n_items == 0) {
             GATMI_HIP(hipMemsetAsync(w.part_y, 0, (size_t)w.waves * 2 * geo.HF * 4, st));
         } else if (a->xs16) {
@@ -3086,23 +3036,37 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     }
     {
         ProfScope ps("inagg_colsums", st);
-        int prow = A.n_items > 0 ? grid * 4 : w.waves;            // partial rows written
-        if (A.n_items > 0 && a->xs16) prow = grid;                  // one partial row per block
-        else if (A.n_items > 0 && group_rows(geo, A)) prow = group_rows_grid(A, grid);
-        else if (A.n_items > 0 && bwd3_covers(geo, H)) prow = grid;
+        int prow = w.waves;                                       // partial rows written
+        if (A.n_items > 0 && a->xs16) prow = w.waves / 4;           // one partial row per block
+        else if (A.n_items > 0 && group_rows(geo, A)) prow = group_rows_grid(A, w.waves / 4);
+        else if (A.n_items > 0 && bwd3_covers(geo, H)) prow = w.waves / 4;
         SumJob j0{w.part_y, w.dwsd, prow, 2 * geo.HF, geo.HF};
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, prow, 2 * geo.HF, geo.HF};
         hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0,
                            j1, j1);
         GATMI_HIP(hipGetLastError());
     }
-    if (side) {
-        GATMI_HIP(hipStreamWaitEvent(st, side->join, 0));
-    } else if (N > 0) {
-        if (int e = dw_gemm(st)) return e;
-    }
     {
-        ProfScope ps("inagg_finalize", st);
+        // slab[split][h] = g[:, h, :]^T Z[:, h, :] over the split's rows
+        ProfScope ps("inagg_dw_gemm", st);
+        if (N > 0) {
+            GemmDesc d{};
+            d.a_kmajor = true; d.b_kmajor = true;
+            d.A = grad_out; d.lda = H * C; d.sA = C;
+            d.B = z; d.ldb = geo.HF; d.sB = geo.Fp;
+            d.C = w.slab; d.ldc = F; d.sC = (long long)C * F; d.sSplit = (long long)H * C * F;
+            d.M = C; d.Nn = F; d.K = N; d.n_store = F; d.nbatch = H; d.nsplit = w.nsplit;
+            d.bias = nullptr; d.sBias = 0;
+            d.fix = AFix{nullptr, nullptr, 1, 1};
+            d.asum = d_bias ? w.gsum : nullptr;   // [h][split][C]: d_bias rides on the staging of g
+            const DwPlan dp = dw_plan(N, H, C, F);
+            if (dp.stream) {
+                dw_stream(dp, grad_out, z, N, H, C, F, geo.Fp, w.slab, d_bias ? w.gsum : nullptr, st);
+                GATMI_HIP(hipGetLastError());
+            } else if (int e = launch_gemm(d, st)) {
+                return e;
+            }
+        }
         const long long tot = (long long)H * C * F;
         const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
         hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab,
