@@ -1,4 +1,4 @@
-"""Two ranks, two processes, one MI355X: the partitioned layer / network (tests/rehearse_gloo2_gpu.py)
+"""Two (and three) ranks, one process each, one MI355X: the partitioned layer / network (tests/rehearse_gloo2_gpu.py)
 and bench.py's N = 2 command line with gloo carrying the collectives between the processes (RCCL cannot
 hold two ranks on one card; RCCL's own call forms are covered at world size 1 by test_a1_*).  The
 children start BEFORE this process touches the GPU (file name: right after test_a0 / test_a1).  A child
@@ -6,6 +6,7 @@ that cannot set up its process group or runs out of time is an environment matte
 skip; a child that ran its checks and found a mismatch fails the test."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -16,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _launch(port, script_args, timeout, extra_env=None):
+def _launch(port, script_args, timeout, extra_env=None, world=2):
     if torch.cuda.device_count() == 0:
         pytest.skip("no GPU")
     if torch.cuda.is_initialized():
@@ -24,16 +25,24 @@ def _launch(port, script_args, timeout, extra_env=None):
     env = dict(os.environ)
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     env.update(extra_env or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    # a session of its own: on a timeout the launcher AND its rank processes are ended (by the group
+    # id of the process started here), none is left behind on the GPU
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                         start_new_session=True)
     try:
-        return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
-    except subprocess.TimeoutExpired as e:
-        pytest.skip(f"two-rank gloo child did not finish in {timeout} s: {str(e.stdout)[-300:]}")
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.skip(f"{world}-rank gloo child did not finish in {timeout} s: {out[-300:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
-def test_two_ranks_on_one_gpu_match_the_single_gpu_layer_and_the_oracle_network():
-    r = _launch(29691, [os.path.join(ROOT, "tests", "rehearse_gloo2_gpu.py")], 280)
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_gpu_match_the_single_gpu_layer_and_the_oracle_network(world):
+    r = _launch(29689 + 2 * world, [os.path.join(ROOT, "tests", "rehearse_gloo2_gpu.py")], 280, world=world)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("ok", "FAILED"))]
     if r.returncode != 0 and not lines:
         pytest.skip("two-rank gloo group could not be created here: " + r.stderr[-400:])
