@@ -221,9 +221,9 @@ def main():
                     "ms_per_step": round(head["ms_per_step"] + 2 * h16["ms_per_step"], 4),
                     "edges_per_s_per_layer": 3 * ep / ((head["ms_per_step"] + 2 * h16["ms_per_step"]) * 1e-3),
                     "note": "f32 input layer + two bf16 hidden layers"}
-            # and the input layer itself on bf16 source rows (gatmi_inagg_table16): same rule
+            # and the input layer itself on bf16 source rows (gatmi_inagg_pack16): same rule
             i16 = measure_layer(args.workload, args, dev, dtype="bf16")
-            if i16["dtype"] == "bf16" and "inagg_table16" in i16["avg"]:
+            if i16["dtype"] == "bf16" and "inagg_pack16" in i16["avg"]:
                 di = max(i16["kb"], key=lambda k: i16["avg"].get(k, 0.0))
                 ai = i16["kb"][di] / (i16["avg"][di] * 1e-3) / 1e9
                 ti, tisrc = measured_traffic(args.workload, di + "_bf16")
@@ -344,7 +344,7 @@ def measure_layer(workload, args, dev, dtype=None):
     text = (f"{workload}-shaped synthetic graph: {n} nodes, {ei.size(1)} edges ({ep} after self-loop "
             f"normalisation), one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
             f"attention dropout {args.dropout} (train mode)")
-    ran_bf16 = "proj16_fwd_gemm" in avg or "inagg_table16" in avg
+    ran_bf16 = "proj16_fwd_gemm" in avg or "inagg_pack16" in avg or "inagg_table16" in avg
     res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, dtype="bf16" if ran_bf16 else "f32",
                kb=kernel_bytes(n, ep, h, d, f, feat_bytes=2 if ran_bf16 else 4),
                ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text, graph_ms=graph_ms)

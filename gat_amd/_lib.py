@@ -156,6 +156,7 @@ SYMBOLS = {
     "gatmi_inagg_pack_workspace_bytes": (C.c_size_t, [C.POINTER(Shape)]),
     "gatmi_inagg_pack": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gatmi_inagg_pack16": (C.c_int, [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gatmi_inagg_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(Shape)]),
     "gatmi_inagg_fwd": (C.c_int, [C.POINTER(Graph), C.POINTER(InAgg), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

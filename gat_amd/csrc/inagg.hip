@@ -2076,7 +2076,7 @@ __global__ void inagg_wsd_kernel(const float *w, const float *att_src, const flo
 template <int KS, int GL>
 __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const float *wsd, long long n,
                                                          int F, int Fp, int Fs, int H, int glog,
-                                                         float *xs, float *a_dst) {
+                                                         float *xs, float *a_dst, uint2 *xs16) {
     constexpr int UN = KS == 1 ? 4 : (KS == 2 ? 2 : 1);   // row groups in flight per wave
     extern __shared__ float s_wsd[];                      // ws | wd, [2][H*Fp]
     const int lane = threadIdx.x & 63, gl = 1 << glog, sl = lane & (gl - 1), rsub = lane >> glog;
@@ -2115,6 +2115,16 @@ __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const f
                 const int sub = sl + k * gl;
                 if (on && sub < lph) stv4(xs + row * Fs + sub * 4, xv[u][k]);
             }
+            // the bf16 table of the same rows (gatmi_inagg_pack16; rows of 256 bytes = 32 uint2: 28
+            // pieces of four channels, zero past Fp, then the f32 logits): the bytes
+            // inagg_table16_kernel makes of xs, without reading xs back.  KS == 1 there (Fp <= 112).
+            if (KS == 1 && xs16 && on) {
+                uint2 *r16 = xs16 + row * (kRow16 / 8);
+                const f4 v = xv[u][0];
+                if (sl < kRow16Logits / 8)
+                    r16[sl] = sl < lph ? make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])) : make_uint2(0u, 0u);
+                for (int sb = sl + gl; sb < kRow16Logits / 8; sb += gl) r16[sb] = make_uint2(0u, 0u);
+            }
             // four heads at a time: the row's logits leave as one float4 per table (the pad of
             // round_up(H, 4) is the zeros of the heads past H)
             for (int h0 = 0; h0 < H; h0 += 4) {
@@ -2138,6 +2148,12 @@ __global__ __launch_bounds__(256) void inagg_pack_kernel(const float *x, const f
                 }
                 if (on && sl == 0) {
                     stv4(xs + row * Fs + Fp + h0, a4);
+                    if (KS == 1 && xs16 && h0 < 8) {
+                        uint4 *l16 = reinterpret_cast<uint4 *>(xs16 + row * (kRow16 / 8) + kRow16Logits / 8);
+                        l16[h0 >> 2] = make_uint4(__float_as_uint(a4[0]), __float_as_uint(a4[1]),
+                                                  __float_as_uint(a4[2]), __float_as_uint(a4[3]));
+                        if (H <= 4) l16[1] = make_uint4(0u, 0u, 0u, 0u);
+                    }
                     if ((H & 3) == 0) {
                         stv4(a_dst + row * H + h0, d4);
                     } else {
@@ -2774,9 +2790,9 @@ extern "C" size_t gatmi_inagg_pack_workspace_bytes(const gatmi_shape *s) {
     return align_up((size_t)2 * geo.HF * 4) + 256;
 }
 
-extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const float *weight,
-                                const float *att_src, const float *att_dst, float *xs, float *a_dst,
-                                void *ws, size_t ws_bytes, void *stream) {
+static int inagg_pack_rows(const gatmi_shape *s, const float *x, const float *weight,
+                           const float *att_src, const float *att_dst, float *xs, float *a_dst,
+                           void *xs16, void *ws, size_t ws_bytes, void *stream) {
     GATMI_REQUIRE(s && x && weight && att_src && att_dst && xs && a_dst, "null argument");
     InGeo geo;
     GATMI_REQUIRE(make_in_geo(*s, &geo), "input-side aggregation does not cover F=%d H=%d",
@@ -2791,7 +2807,7 @@ extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *wsd = static_cast<float *>(ws);
     const int H = s->heads, C = s->channels, F = s->in_features;
-    ProfScope ps("inagg_pack", st);
+    ProfScope ps(xs16 ? "inagg_pack16" : "inagg_pack", st);
     hipLaunchKernelGGL(inagg_wsd_kernel, dim3((2 * geo.HF + 255) / 256), dim3(256), 0, st, weight,
                        att_src, att_dst, H, C, F, geo.Fp, wsd);
     GATMI_HIP(hipGetLastError());
@@ -2807,7 +2823,9 @@ extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const floa
     const size_t lds = (size_t)2 * geo.HF * sizeof(float);
 #define GATMI_PACK(KS, GL)                                                                       \
     hipLaunchKernelGGL((inagg_pack_kernel<KS, GL>), dim3((unsigned)blocks), dim3(256), lds, st, x, wsd, n, \
-                       F, geo.Fp, geo.Fs, H, glog, xs, a_dst)
+                       F, geo.Fp, geo.Fs, H, glog, xs, a_dst, static_cast<uint2 *>(xs16))
+    GATMI_REQUIRE(!xs16 || (ks == 1 && rows16_cover(geo, H)),
+                  "bf16 source rows cover F <= 112 with H <= 4, or 5..8 heads and F > 32 (got F=%d H=%d)", F, H);
     if (ks == 1 && gl == 32) GATMI_PACK(1, 32);         // F = 65 .. 128: the layers BASELINE.json names
     else if (ks == 1 && gl == 8) GATMI_PACK(1, 8);      // run.py's 25 features
     else if (ks == 1) GATMI_PACK(1, 0);
@@ -2816,6 +2834,19 @@ extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const floa
 #undef GATMI_PACK
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
+}
+
+extern "C" int gatmi_inagg_pack(const gatmi_shape *s, const float *x, const float *weight,
+                                const float *att_src, const float *att_dst, float *xs, float *a_dst,
+                                void *ws, size_t ws_bytes, void *stream) {
+    return inagg_pack_rows(s, x, weight, att_src, att_dst, xs, a_dst, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int gatmi_inagg_pack16(const gatmi_shape *s, const float *x, const float *weight,
+                                  const float *att_src, const float *att_dst, float *xs, float *a_dst,
+                                  void *xs16, void *ws, size_t ws_bytes, void *stream) {
+    GATMI_REQUIRE(xs16, "null xs16");
+    return inagg_pack_rows(s, x, weight, att_src, att_dst, xs, a_dst, xs16, ws, ws_bytes, stream);
 }
 
 extern "C" size_t gatmi_inagg_xs16_bytes(const gatmi_shape *s) {

@@ -66,9 +66,12 @@ class _GATConvInAggFn(torch.autograd.Function):
         att_d = att_dst.contiguous().view(-1)
         bias_c = None if bias is None else bias.contiguous()
         need_grad = any(ctx.needs_input_grad[1:5])
-        xs, a_dst = ops.inagg_pack(x, weight, att_s, att_d, cfg.heads, cfg.channels)
-        # bf16 source rows for the gathers (cfg.rows16): the f32 table stays for the row-local terms
-        xs16 = ops.inagg_table16(xs, x.size(1), cfg.heads, cfg.channels) if getattr(cfg, "rows16", False) else None
+        # bf16 source rows for the gathers (cfg.rows16) come out of the pack kernel with the f32 table,
+        # which stays for the row-local terms
+        if getattr(cfg, "rows16", False):
+            xs, a_dst, xs16 = ops.inagg_pack(x, weight, att_s, att_d, cfg.heads, cfg.channels, rows16=True)
+        else:
+            (xs, a_dst), xs16 = ops.inagg_pack(x, weight, att_s, att_d, cfg.heads, cfg.channels), None
         out, z, lse = ops.inagg_fwd(layout, cfg, xs, a_dst, weight, att_s, att_d, bias_c, need_grad, xs16)
         if need_grad:
             ctx.save_for_backward(xs, a_dst, weight, att_s, att_d, bias_c, z, lse, xs16)

@@ -425,8 +425,10 @@ def inagg_supported(in_features: int, heads: int, channels: int, edges_per_node:
 
 
 def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, heads: int,
-               channels: int) -> Tuple[Tensor, Tensor]:
-    """rows of x -> packed source rows xs [n, Fs] (x | a_src | pad) and a_dst [n, H]."""
+               channels: int, rows16: bool = False):
+    """rows of x -> packed source rows xs [n, Fs] (x | a_src | pad) and a_dst [n, H].  rows16: also the
+    bf16 table of those rows (gatmi_inagg_pack16: what inagg_table16(xs) would make, written by the
+    same kernel) -> (xs, a_dst, xs16)."""
     lib, dev = _lib.lib(), x.device
     n, f = x.shape
     shape = _lib.Shape(n, f, heads, channels)
@@ -439,6 +441,17 @@ def inagg_pack(x: Tensor, weight: Tensor, att_src: Tensor, att_dst: Tensor, head
         xs = torch.empty(n, fs, dtype=torch.float32, device=dev)
         a_dst = torch.empty(n, heads, dtype=torch.float32, device=dev)
         ws = _ws(lib.gatmi_inagg_pack_workspace_bytes(C.byref(shape)), dev)
+        if rows16:
+            row = int(lib.gatmi_inagg_xs16_bytes(C.byref(shape)))
+            if row == 0:
+                raise RuntimeError(f"bf16 source rows do not cover F={f} H={heads}")
+            xs16 = torch.empty(n, row // 2, dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.gatmi_inagg_pack16(C.byref(shape), x.data_ptr(), weight.data_ptr(),
+                                              att_src.data_ptr(), att_dst.data_ptr(), xs.data_ptr(),
+                                              a_dst.data_ptr(), xs16.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _stream(dev)),
+                       "gatmi_inagg_pack16")
+            return xs, a_dst, xs16
         _lib.check(lib.gatmi_inagg_pack(C.byref(shape), x.data_ptr(), weight.data_ptr(),
                                         att_src.data_ptr(), att_dst.data_ptr(), xs.data_ptr(),
                                         a_dst.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),

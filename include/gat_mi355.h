@@ -321,6 +321,12 @@ int gatmi_inagg_pack(const gatmi_shape *s /* num_nodes = rows to pack */, const 
  * stated in tests/test_gpu_bf16.py).  gatmi_inagg_xs16_bytes: bytes per row (256), 0 when the
  * shape is not covered (F <= 112; H <= 4, or 5..8 heads with F > 32).  gatmi_inagg_table16: xs [num_nodes, Fs] -> xs16. */
 size_t gatmi_inagg_xs16_bytes(const gatmi_shape *s);
+/* gatmi_inagg_pack that also writes the bf16 table of the rows it packs (the same bytes
+ * gatmi_inagg_table16 makes of xs, without the pass that reads xs back). */
+int gatmi_inagg_pack16(const gatmi_shape *s /* num_nodes = rows to pack */, const float *x,
+                       const float *weight, const float *att_src, const float *att_dst,
+                       float *xs /* [rows, Fs] */, float *a_dst /* [rows, H] */,
+                       void *xs16 /* [rows, 256 bytes] */, void *ws, size_t ws_bytes, void *stream);
 int gatmi_inagg_table16(const gatmi_shape *s /* num_nodes = rows */, const float *xs, void *xs16,
                         void *stream);
 

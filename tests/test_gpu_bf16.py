@@ -276,7 +276,7 @@ def test_bf16_tables_are_refused_for_narrow_rows(cuda):
                                        (1500, 48, 6, 20, 0.0)])
 def test_input_side_path_on_bf16_source_rows(cuda, kind, n, f, h, c, p):
     """GATConv(feature_dtype=torch.bfloat16) on the input-side aggregation path (x is data: no d_x):
-    the edge kernels gather a bf16 copy of the packed x rows (gatmi_inagg_table16, 256-byte rows); the
+    the edge kernels gather a bf16 copy of the packed x rows (gatmi_inagg_pack16, 256-byte rows); the
     logits, the softmax, Z, q and every output stay f32.  Bar (1): fed an x that bf16 holds exactly,
     the table is exact and the layer meets the f32 bar against the oracle.  Bar (2): on any x, the
     stated bf16 tolerance against the f32 oracle."""
@@ -301,7 +301,7 @@ def test_input_side_path_on_bf16_source_rows(cuda, kind, n, f, h, c, p):
         out.backward(go.to(cuda))
         torch.cuda.synchronize(); _lib.prof_enable(False)
         tags = {t for t, _ in _lib.prof_read()}
-        assert {"inagg_table16", "inagg_fwd", "inagg_bwd_edge"} <= tags, tags
+        assert {"inagg_pack16", "inagg_fwd", "inagg_bwd_edge"} <= tags and "inagg_table16" not in tags, tags
         grads = dict(weight=conv.lin.weight.grad, att_src=conv.att_src.grad, att_dst=conv.att_dst.grad,
                      bias=conv.bias.grad)
         if exact:
@@ -312,6 +312,22 @@ def test_input_side_path_on_bf16_source_rows(cuda, kind, n, f, h, c, p):
             check_bf16_tolerance(out, grads, ref_out, ref_g)
 
 
+@pytest.mark.parametrize("n,f,h,c", [(1003, 100, 4, 64), (517, 64, 8, 32), (300, 40, 8, 16), (2050, 112, 3, 24),
+                                     (65, 72, 2, 64), (1, 36, 4, 16), (4097, 57, 4, 64), (700, 33, 5, 8)])
+def test_pack_kernel_writes_the_same_bf16_table_as_the_conversion_pass(cuda, n, f, h, c):
+    """gatmi_inagg_pack16 against gatmi_inagg_pack + gatmi_inagg_table16: xs, a_dst and every byte of
+    the 256-byte rows (x pieces, the zero padding behind them, the f32 logits of up to eight heads)."""
+    from gat_amd import ops
+    assert ops.inagg_rows16_supported(f, h, c)
+    x, w, a_s, a_d, _, _ = cases.layer_inputs(n, f, h, c, seed=n + f)
+    x, w, a_s, a_d = (t.to(cuda) for t in (x, w, a_s.view(-1), a_d.view(-1)))
+    xs, a_dst = ops.inagg_pack(x, w, a_s, a_d, h, c)
+    table = ops.inagg_table16(xs, f, h, c)
+    xs2, a_dst2, table2 = ops.inagg_pack(x, w, a_s, a_d, h, c, rows16=True)
+    assert torch.equal(xs, xs2) and torch.equal(a_dst, a_dst2)
+    assert table2.shape == table.shape and torch.equal(table.view(torch.int16), table2.view(torch.int16))
+
+
 def test_bf16_source_rows_are_refused_where_not_covered(cuda):
     from gat_amd import GATConv, _lib, ops
     assert not ops.inagg_rows16_supported(25, 8, 30) and not ops.inagg_rows16_supported(120, 4, 64)
@@ -320,7 +336,7 @@ def test_bf16_source_rows_are_refused_where_not_covered(cuda):
     _lib.prof_read(); _lib.prof_enable(True)
     conv(torch.randn(n, 25, device=cuda), ei.to(cuda))
     torch.cuda.synchronize(); _lib.prof_enable(False)
-    assert "inagg_table16" not in {t for t, _ in _lib.prof_read()}       # f32 rows, as before
+    assert not {"inagg_table16", "inagg_pack16"} & {t for t, _ in _lib.prof_read()}       # f32 rows, as before
 
 
 def test_random_graphs_on_bf16_source_rows(cuda):
