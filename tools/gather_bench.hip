@@ -82,6 +82,55 @@ __global__ __launch_bounds__(256, 4) void gather1k_kernel(const char *__restrict
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
 }
 
+// the same with the projected-row forward's output: per 26 gathered rows one 1024-byte row is written
+// (SM 0 plain, 1 nontemporal, 2 plain but only every row's first line, 3 none)
+template <int U, int SM>
+__global__ __launch_bounds__(256, 4) void gather1k_store_kernel(const char *__restrict__ rows, const int *__restrict__ idx,
+                                                                int n_items, int deg, float *__restrict__ dst,
+                                                                float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    f4 keep = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+    int prev_it = 0;
+    bool have_prev = false;
+    for (int it = wave; it < n_items; it += nwaves) {
+        const long long c = (long long)it * deg;
+        const int n = deg;
+        const int cj = idx[c + (lane < n ? lane : n - 1)];
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        auto load = [&](f4(&v)[U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = __builtin_amdgcn_readlane(cj, k0 + u < n ? k0 + u : n - 1);
+                v[u] = *reinterpret_cast<const f4 *>(rows + (size_t)j * 1024 + lane * 16);
+            }
+        };
+        f4 va[U], vb[U];
+        load(va, 0);
+        if (SM == 4) {
+            // the PREVIOUS item's row leaves now, behind this item's first loads: the waits on those
+            // loads (vmcnt counts loads and stores in issue order on gfx9) no longer include its ack
+            if (have_prev) *reinterpret_cast<f4 *>(dst + (size_t)prev_it * 256 + lane * 4) = prev;
+        }
+        for (int k0 = 0; k0 < n; k0 += 2 * U) {
+            load(vb, k0 + U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += va[u];
+            load(va, k0 + 2 * U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += vb[u];
+        }
+        f4 *d = reinterpret_cast<f4 *>(dst + (size_t)it * 256 + lane * 4);
+        if (SM == 0) *d = acc;
+        else if (SM == 1) __builtin_nontemporal_store(acc, d);
+        else if (SM == 2) { if (lane < 8) *d = acc; else keep += acc; }
+        else if (SM == 4) { prev = acc; prev_it = it; have_prev = true; }
+        else keep += acc;
+    }
+    if (SM == 4 && have_prev) *reinterpret_cast<f4 *>(dst + (size_t)prev_it * 256 + lane * 4) = prev;
+    if (keep[0] + keep[1] + keep[2] + keep[3] == 12345.678f) out[0] = keep[0];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // From the pure gather towards inagg_fwd3_kernel, one ingredient at a time, on a uniform-degree CSR
 // (row r owns edges [deg r, deg (r + 1))): which ingredient costs what.
@@ -315,6 +364,33 @@ int main() {
         printf("1024-byte rows (eight lines), one row per instruction, U=%d  %7.3f ms  %6.2f G edges/s  useful %5.2f TB/s\n",
                uu == 0 ? 2 : (uu == 1 ? 4 : 8), best, (double)E / best / 1e6, (double)E * 1028 / best / 1e9);
         fflush(stdout);
+    }
+    {
+        const int deg = 26, n_items = (int)(E / deg);
+        float *dst;
+        CHECK(hipMalloc(&dst, (size_t)n_items * 1024 + 1024));
+        const char *nm[] = {"plain 1-KiB row stores", "nontemporal stores", "only the first line of every row stored", "no stores",
+                            "row stored behind the next item's first loads"};
+        for (int sm = 0; sm < 5; ++sm) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CHECK(hipEventRecord(e0, 0));
+                if (sm == 0) hipLaunchKernelGGL((gather1k_store_kernel<4, 0>), dim3(2048), dim3(256), 0, 0, rows, idx, n_items, deg, dst, out);
+                else if (sm == 1) hipLaunchKernelGGL((gather1k_store_kernel<4, 1>), dim3(2048), dim3(256), 0, 0, rows, idx, n_items, deg, dst, out);
+                else if (sm == 2) hipLaunchKernelGGL((gather1k_store_kernel<4, 2>), dim3(2048), dim3(256), 0, 0, rows, idx, n_items, deg, dst, out);
+                else if (sm == 3) hipLaunchKernelGGL((gather1k_store_kernel<4, 3>), dim3(2048), dim3(256), 0, 0, rows, idx, n_items, deg, dst, out);
+                else hipLaunchKernelGGL((gather1k_store_kernel<4, 4>), dim3(2048), dim3(256), 0, 0, rows, idx, n_items, deg, dst, out);
+                CHECK(hipGetLastError());
+                CHECK(hipEventRecord(e1, 0));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep > 0 && ms < best) best = ms;
+            }
+            printf("1024-byte rows, 26 per item, %-42s %7.3f ms\n", nm[sm], best);
+            fflush(stdout);
+        }
+        CHECK(hipFree(dst));
     }
     // ---- the ladder on a uniform-degree CSR (26 edges per destination row)
     {
