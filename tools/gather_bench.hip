@@ -131,6 +131,26 @@ __global__ __launch_bounds__(256, 4) void gather1k_store_kernel(const char *__re
     if (keep[0] + keep[1] + keep[2] + keep[3] == 12345.678f) out[0] = keep[0];
 }
 
+// streams: read-only, write-only, copy (what a written byte costs next to a read one, no gathers involved)
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_kernel(const f4 *__restrict__ src, f4 *__restrict__ dst, long long n4,
+                                                     float *__restrict__ out) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long k = i + u * stride;
+            if (k < n4) {
+                if (MODE == 0) acc += src[k];
+                else if (MODE == 1) dst[k] = f4{1.f, 2.f, 3.f, (float)u};
+                else dst[k] = src[k];
+            }
+        }
+    }
+    if (MODE == 0 && acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // From the pure gather towards inagg_fwd3_kernel, one ingredient at a time, on a uniform-degree CSR
 // (row r owns edges [deg r, deg (r + 1))): which ingredient costs what.
@@ -391,6 +411,33 @@ int main() {
             fflush(stdout);
         }
         CHECK(hipFree(dst));
+    }
+    {
+        const long long bytes = 3900000000ll, n4 = bytes / 16;
+        f4 *a, *b;
+        CHECK(hipMalloc(&a, bytes));
+        CHECK(hipMalloc(&b, bytes));
+        CHECK(hipMemset(a, 0, bytes));
+        const char *nm[] = {"read 3.9 GB", "write 3.9 GB", "copy 3.9 GB (read + write)"};
+        for (int mode = 0; mode < 3; ++mode) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CHECK(hipEventRecord(e0, 0));
+                if (mode == 0) hipLaunchKernelGGL((stream_kernel<0>), dim3(8192), dim3(256), 0, 0, a, b, n4, out);
+                else if (mode == 1) hipLaunchKernelGGL((stream_kernel<1>), dim3(8192), dim3(256), 0, 0, a, b, n4, out);
+                else hipLaunchKernelGGL((stream_kernel<2>), dim3(8192), dim3(256), 0, 0, a, b, n4, out);
+                CHECK(hipGetLastError());
+                CHECK(hipEventRecord(e1, 0));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep > 0 && ms < best) best = ms;
+            }
+            printf("stream: %-30s %7.3f ms  %5.2f TB/s\n", nm[mode], best, (mode == 2 ? 2.0 : 1.0) * bytes / best / 1e9);
+            fflush(stdout);
+        }
+        CHECK(hipFree(a));
+        CHECK(hipFree(b));
     }
     // ---- the ladder on a uniform-degree CSR (26 edges per destination row)
     {
