@@ -2424,6 +2424,639 @@ __global__ __launch_bounds__(256) void inagg_finalize_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// Fused tiles of the row-per-lane-group layout: run.py's conv1, 25 -> 8 x 30 on
+// a 5-nearest-neighbour graph, and its neighbours in the reference's searches (5..8 heads, rows
+// of at most 8 float4, C <= 64, no row cut into segments).  A block owns tiles of 32 CONSECUTIVE
+// destination rows, a wave 8 of them (one per 8-lane group, as in inagg_fwdg / inagg_bwdg), and
+// the products that the separate GEMMs made of whole [N, H*Fp] tensors are MFMA tiles of the
+// block, each wave multiplying the two heads 2 wv, 2 wv + 1:
+//   forward   Z tile (registers -> LDS) -> out tile = Z W^T + bias        (Z still goes to HBM once:
+//             the backward reads it for S and d_W; the out GEMM's re-read of it is gone)
+//   backward  g tile (HBM -> the wave's LDS) -> q tile = g W (-> LDS, never in HBM),
+//             d_W += g^T Z and the column sums of g in persistent accumulators, then the edge
+//             pass of the tile with q from LDS.  One slab of d_W per block, summed by
+//             inagg_finalize_kernel as the split-K slabs were.
+// MFMA operands (v_mfma_f32_32x32x2_f32): a lane supplies A[m = lane % 32][k = lane / 32].  Tiles
+// whose m is the ROW index are read from LDS as ds_read_b64 -- two consecutive k of one row,
+// used as two MFMA steps (the K order of a product is free as long as A and B agree) -- with a
+// row stride of 2 mod 4 floats: 32 rows x 2 banks cover the 64 banks once.
+// ---------------------------------------------------------------------------------
+struct FuseArgs {
+    const float *w;      // [H*C, F]
+    const float *wimg;   // forward: [H][Fp][32 CT] = W^T per head, zero padded (inagg_wimg_kernel)
+    const float *bias;   // [H*C] or null (forward)
+    const float *gout;   // grad_out [N, H*C] (backward)
+    float *out;          // [N, H*C] (forward)
+    float *slab;         // [blocks][H][C][F] (backward)
+    float *gsum;         // [H][blocks][C] or null (backward)
+    int C, F, N, ntiles;
+    int dbg;             // GATMI_FUSE_DBG: ablation bits (wrong results; timing only)
+    int zs;              // forward: row stride of the Z tile; backward: of the q tile (floats)
+    int gs, cp4;         // backward: row stride of a wave's g tile, columns per head in it
+    int lpr_log;         // backward: log2 of the lanes that load one head's columns of a row of grad_out
+};
+
+__device__ __forceinline__ void st_lds2(float *p, float a, float b) {
+    *reinterpret_cast<f2 *>(p) = f2{a, b};
+}
+
+// Barrier of the block for LDS hand-overs only: waits for the wave's LDS operations, not for its
+// global stores (__syncthreads drains vmcnt too: the Z and out rows of a tile would be waited for
+// twice per tile)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// What a lane needs of its row before the first gather of a tile, fetched one tile ahead: the
+// rowptr pair and the row's a_dst / lse while the tile before is in its edge pass, col and keep
+// bits of the first 8 edges while it is in its products -- a tile then starts with the gathers
+// themselves instead of a chain of three dependent loads
+struct TileMeta {
+    int beg, end, cj, kb;
+    float adi, lse;
+};
+
+// wimg[h][k][c] = W[h C + c][k] for c < C, k < F, else 0 (k < Fp, c < cw = 32 CT)
+__global__ void inagg_wimg_kernel(const float *w, int H, int C, int F, int Fp, int cw, float *wimg) {
+    const int tot = H * Fp * cw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) {
+        const int c = i % cw, k = (i / cw) % Fp, h = i / (cw * Fp);
+        wimg[i] = (c < C && k < F) ? w[((size_t)h * C + c) * F + k] : 0.f;
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 3) void inagg_fwdgf_kernel(const InArgs A, const FuseArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
+    float *zt = fuse_lds;                                         // [32 rows][zs]
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
+    const int lane = threadIdx.x & 63, g = lane >> 3, p = lane & 7;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: heads, LDS corners and offsets follow from it
+    const int l = lane & 31, half = lane >> 5;
+    const int hl_raw = head_of_lane<3>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    const unsigned hbit = 1u << hl;
+    // B operands of out[:, h, :] = Z[:, h, :] W_h^T for the wave's two heads: lane (n = l, half)
+    // holds W[h C + c][k] for the k pairs 4 t + 2 half, + 1 the A reads deliver.  Loaded per tile
+    // (24 KiB of weights: cache hits) once the edge pass has let go of its registers, ahead of the barrier
+    auto load_wf = [&](float (&wf)[2][CT][16], const float *wimg) {
+        // from the k-major image inagg_wimg_kernel makes of W ([H][Fp][32 CT], zero padded): a
+        // half-wave reads 128 consecutive bytes (from W itself each lane would touch a line of its
+        // own: 64 tag look-ups an instruction, 2048 a tile and wave -- the kernel was bound by them);
+        // head, k and column tile in the scalar offset, the quads past Fp run off the image and read 0
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(wimg), 0, A.H * A.Fp * CT * 32 * 4, 0x00020000);
+        const int vo = (2 * half * CT * 32 + l) * 4;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = min(2 * wv + hh, A.H - 1);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int so = t < A.lph ? (((h * A.Fp + 4 * t + j) * CT + ct) * 32) * 4 : 0x7ffffff0;
+                        wf[hh][ct][2 * t + j] =
+                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, vo, so, 0));
+                    }
+        }
+    };
+    auto meta_row = [&](int tile, TileMeta &M) {
+        const int row = tile * 32 + wv * 8 + g;
+        const bool on = tile < P.ntiles && row < P.N;
+        M.beg = M.end = 0;
+        if (on) {
+            M.beg = A.rowptr[row];
+            M.end = A.rowptr[row + 1];
+        }
+        M.adi = A.a_dst[(size_t)(on ? row : 0) * A.H + hl];
+    };
+    auto meta_cols = [&](TileMeta &M) {
+        const int n = min(max(M.end - M.beg, 0), 8);
+        const int el = M.beg + min(p, max(n - 1, 0));
+        M.cj = n > 0 ? A.col[el] : 0;
+        M.kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+    };
+    int tile = xcd_contiguous_block();
+    TileMeta N1;
+    meta_row(tile, N1);
+    meta_cols(N1);
+    for (; tile < P.ntiles; tile += gridDim.x) {
+        const int row = tile * 32 + wv * 8 + g;
+        const bool on = row < P.N;
+        const TileMeta M = N1;
+        meta_row(tile + gridDim.x, N1);                           // in flight across the edge pass
+        const int beg = M.beg, end = M.end;
+        const float adi = M.adi;
+        float m = -INFINITY, ssum = 0.f;
+        f4 acc[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) acc[h] = zero4();
+        const int nmax = __builtin_amdgcn_readfirstlane(groups_max_i(end - beg));
+        for (int c = 0; c < nmax; c += 8) {
+            const int n = min(max(end - beg - c, 0), 8);          // this group's edges of the chunk
+            const int nw = min(nmax - c, 8);                      // the wave's longest
+            int cj = M.cj, kb = M.kb;
+            if (c > 0) {                                          // wave-uniform
+                const int el = beg + c + min(p, max(n - 1, 0));
+                cj = n > 0 ? A.col[el] : 0;
+                kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+            }
+            f4 v[8];
+            float z[8];
+            unsigned sb[8];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                z[e] = -INFINITY;
+                if (e < nw) {                                     // wave-uniform
+                    const int src = (lane & 56) | min(e, max(n - 1, 0));
+                    const int j = __shfl(cj, src, 64);
+                    sb[e] = (unsigned)__shfl(kb, src, 64);
+                    v[e] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                    const float uu = A.xs[(size_t)j * A.Fs + A.Fp + hl] + adi;
+                    z[e] = e < n ? (uu > 0.f ? uu : A.neg_slope * uu) : -INFINITY;
+                }
+                zmax = fmaxf(zmax, z[e]);
+            }
+            const float mn = fmaxf(m, zmax);
+            const float sc = mn == -INFINITY ? 1.0f : exp_quick(m - mn);
+            float psum = 0.f, w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                w[e] = 0.f;
+                if (e < nw) {
+                    const float pe = e < n ? exp_quick(z[e] - mn) : 0.f;
+                    psum += pe;
+                    w[e] = (sb[e] & hbit) ? pe * A.inv_keep : 0.f;
+                }
+            }
+            ssum = fmaf(ssum, sc, psum);
+            m = mn;
+            if (c > 0) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) pk_scale4(acc[h], bcast_head<3>(sc, h));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < nw) {
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) pk_fma4(acc[h], bcast_head<3>(w[e], h), v[e]);
+                }
+        }
+        meta_cols(N1);                                            // in flight across the products
+        const float inv = ssum > 0.f ? 1.0f / ssum : 0.f;
+        // Sizes the compiler cannot see through: everything derived from them (lane addresses of the
+        // weight loads, of the tile reads and of the 16 output rows) is loop-invariant, would be
+        // hoisted out of the tile loop, held across the edge pass and spilled
+        int zs = P.zs, C = P.C, F = P.F;
+        asm volatile("" : "+s"(zs), "+s"(C), "+s"(F));
+        const int HCl = A.H * C;
+        const int trows = min(32, P.N - tile * 32);
+        lds_barrier();                                            // the tile before has left the LDS
+        // the Z row -> the LDS tile (zeros past N); it goes to HBM from there
+        float *ztr = zt + (wv * 8 + g) * zs + p * 4;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const float ivh = bcast_head<3>(inv, h);
+            if (pok && h < A.H) {
+                f4 o = acc[h];
+                pk_scale4(o, ivh);
+                st_lds2(ztr + h * A.Fp, o[0], o[1]);
+                st_lds2(ztr + h * A.Fp + 2, o[2], o[3]);
+            }
+        }
+        if (on && A.lse && hlok) A.lse[(size_t)row * A.H + hl] = m + logf(ssum);
+        float wf[2][CT][16];
+        load_wf(wf, P.wimg + (zs - P.zs));
+        lds_barrier();                                            // the Z tile is whole
+        // Z rows of the tile are one contiguous block of HBM: whole lines, 512 bytes a wave
+        // instruction (stored from the edge pass they were 112-byte pieces of 8 rows an instruction:
+        // 3.9 TB/s, and the out rows in 120-byte pieces off the MFMA fragments 2.1 TB/s)
+        {
+            const int hf2 = HF >> 1;                              // float2 per row
+            float *zg = A.z + (size_t)tile * 32 * HF;
+            for (int r = wv; r < trows; r += 4)
+                for (int c2 = lane; c2 < hf2; c2 += 64)
+                    *reinterpret_cast<f2 *>(zg + r * HF + 2 * c2) = *reinterpret_cast<const f2 *>(zt + r * zs + 2 * c2);
+        }
+        f32x16 d[2][CT];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = min(2 * wv + hh, A.H - 1);
+            const float *ap = zt + l * zs + h * A.Fp + 2 * half;
+            // branch-free: the quads past the row re-read its last one against zero weights
+            f2 a2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a2[t] = *reinterpret_cast<const f2 *>(ap + 4 * min(t, A.lph - 1));
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[hh][ct][r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    d[hh][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t].x, wf[hh][ct][2 * t], d[hh][ct], 0, 0, 0);
+                    d[hh][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t].y, wf[hh][ct][2 * t + 1], d[hh][ct], 0, 0, 0);
+                }
+            }
+        }
+        lds_barrier();                                            // the Z tile has been read
+        // out tile = products + bias -> LDS as the image of its 32 rows in HBM (over the Z tile)
+        float *ot = fuse_lds;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * wv + hh;
+            if (h < A.H) {                                        // wave-uniform
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 32 + l;
+                    if (c < C) {
+                        const float bv = P.bias ? P.bias[h * C + c] : 0.f;
+                        float *op = ot + 4 * half * HCl + h * C + c;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) op[((r & 3) + 8 * (r >> 2)) * HCl] = d[hh][ct][r] + bv;
+                    }
+                }
+            }
+        }
+        lds_barrier();                                            // the out tile is whole
+        {
+            float *og = P.out + (size_t)tile * 32 * HCl;
+            const int n4 = trows * HCl >> 2;                      // 32 HC is a multiple of 4; a ragged last tile
+            for (int i = threadIdx.x; i < n4; i += 256)           // with HC % 4 != 0 ends in single floats
+                stv4(og + 4 * i, ldv4(ot + 4 * i));
+            for (int i = 4 * n4 + threadIdx.x; i < trows * HCl; i += 256) og[i] = ot[i];
+        }
+    }
+}
+
+template <int CT, int VW>
+__global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, const FuseArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
+    // LDS: q of the tile [32 rows][zs] | per wave: g, its two heads [32 rows][gs] | per wave: [8][8]
+    const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
+    const int lane = threadIdx.x & 63, g = lane >> 3, p = lane & 7;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: heads, LDS corners and offsets follow from it
+    const int l = lane & 31, half = lane >> 5;
+    const int hl_raw = head_of_lane<3>(lane);
+    const bool hlok = hl_raw < A.H;
+    const int hl = hlok ? hl_raw : 0;
+    const bool pok = p < A.lph;
+    const unsigned offp = pok ? (unsigned)p * 16u : 0u;
+    const int HF = A.H * A.Fp;
+    const size_t row_bytes = (size_t)A.Fs * 4;
+    const char *xsb = reinterpret_cast<const char *>(A.xs);
+    const unsigned hbit = 1u << hl;
+    const int h0 = 2 * wv;
+    const int nh = max(min(2, A.H - h0), 0);                      // heads this wave multiplies
+    constexpr int K4 = CT * 8;                                    // k quads of q = g W (C <= 32 CT)
+    for (int i = lane; i < 32 * P.gs; i += 64)                    // the pad columns stay zero
+        fuse_lds[32 * P.zs + wv * 32 * P.gs + i] = 0.f;
+    // B operands of q[:, h, :] = g[:, h, :] W_h: lane (half, n = l) holds W[h C + k][l] for the k
+    // pairs 4 t + 2 half, + 1.  Loaded per tile (cache hits): held across the edge pass they spill
+    float wq[2][2 * K4];
+    auto load_wq = [&](const float *wbase, int C, int F, int nk4) {
+        // branch-free: a buffer over each head's block of W, row k (scalar offset) at column l (one
+        // lane offset); rows beyond C run past the block and read 0, as do the columns beyond F
+        const int vo = l < F ? (2 * half * F + l) * 4 : 0x7ffffff0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(wbase) + (size_t)min(h0 + hh, A.H - 1) * C * F, 0, C * F * 4, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < K4; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    wq[hh][2 * t + j] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(wrs, vo, (4 * t + j) * F * 4, 0));
+        }
+    };
+    auto meta_row = [&](int tile, TileMeta &M) {
+        const int row = tile * 32 + wv * 8 + g;
+        const bool on = tile < P.ntiles && row < P.N;
+        M.beg = M.end = 0;
+        if (on) {
+            M.beg = A.rowptr[row];
+            M.end = A.rowptr[row + 1];
+        }
+        M.adi = A.a_dst[(size_t)(on ? row : 0) * A.H + hl];
+        M.lse = A.lsein[(size_t)(on ? row : 0) * A.H + hl];
+    };
+    auto meta_cols = [&](TileMeta &M) {
+        const int n = min(max(M.end - M.beg, 0), 8);
+        const int el = M.beg + min(p, max(n - 1, 0));
+        M.cj = n > 0 ? A.col[el] : 0;
+        M.kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+    };
+    f32x16 dw[2][CT];
+    float gsa[2][CT];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            gsa[hh][ct] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw[hh][ct][r] = 0.f;
+        }
+    f4 ys[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) ys[h] = zero4();
+    f32x4t ydm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d_wd [head][f] by 16x16x4 MFMAs, f < 16 | f >= 16
+    int tile = xcd_contiguous_block();
+    TileMeta N1;
+    meta_row(tile, N1);
+    meta_cols(N1);
+    for (; tile < P.ntiles; tile += gridDim.x) {
+        const int row0 = tile * 32;
+        // Sizes the compiler cannot see through: what is derived from them (lane addresses of the
+        // weight loads, of the tile reads and stores) is loop-invariant, would be hoisted out of the
+        // tile loop, held across the edge pass and spilled
+        int zs = P.zs, gs = P.gs, cp4 = P.cp4, C = P.C, F = P.F;
+        asm volatile("" : "+s"(zs), "+s"(gs), "+s"(cp4), "+s"(C), "+s"(F));
+        const int HC = A.H * C, nk4 = cp4 >> 2;
+        float *qt = fuse_lds;
+        float *gtw = fuse_lds + 32 * zs + wv * 32 * gs;
+        float *dtw = fuse_lds + 32 * zs + 4 * 32 * gs + wv * 64;
+        const int row = row0 + wv * 8 + g;
+        const bool on = row < P.N;
+        // 0. everything the tile reads from HBM before its edge pass is issued here, one latency for
+        //    all of it: the Z rows of the wave's 8 destinations (for S), the Z tile of its heads (B
+        //    of d_W), its weight fragments, its columns of grad_out.  Buffer loads over the tile's
+        //    rows: one lane offset per kind of load, the rest in scalar offsets, rows past N read 0.
+        const int trows = min(32, P.N - row0);
+        const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(A.zin) + (size_t)row0 * HF, 0, trows * HF * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(P.gout) + (size_t)row0 * HC, 0, trows * HC * 4, 0x00020000);
+        constexpr int kOob = 0x7ffffff0;                          // an offset past every tile: the load returns 0
+        const int zvo = l < A.Fp ? (half * HF + l) * 4 : kOob;    // B of d_W: Z[row 2 s + half][h Fp + l]
+        auto load_zb = [&](int hh, float (&zb)[16]) {
+            const int so = min(h0 + hh, A.H - 1) * A.Fp * 4;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                zb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvo, so + 2 * s * HF * 4, 0));
+        };
+        float zb[16];
+        load_zb(0, zb);
+        // 1. the wave's columns of 32 rows of grad_out -> its LDS tile: per head, LPR lanes a row
+        //    (VW floats each), 64 / LPR rows an instruction
+        {
+            const int lpr_log = P.lpr_log, rpi = 64 >> lpr_log, ni = 32 >> (6 - lpr_log);
+            const int le = lane & ((1 << lpr_log) - 1), lr = lane >> lpr_log;
+            const bool eok = le * VW < C;
+            const int gvo = eok ? (lr * HC + le * VW) * 4 : kOob;
+            float *gl = gtw + lr * gs + le * VW;
+            constexpr int NI = CT * 16 / VW;                      // instructions per head at most
+            auto stage = [&](int hh, float (&vv)[NI][VW]) {
+                const int so = (h0 + hh) * C * 4;
+#pragma unroll
+                for (int u = 0; u < NI; ++u)
+                    if (u < ni) {                                 // wave-uniform
+                        const int sof = so + u * rpi * HC * 4;
+                        if constexpr (VW == 4) {
+                            const f4 t4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(grs, gvo, sof, 0));
+                            vv[u][0] = t4[0]; vv[u][1] = t4[1]; vv[u][2] = t4[2]; vv[u][3] = t4[3];
+                        } else if constexpr (VW == 2) {
+                            const f2 t2 = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(grs, gvo, sof, 0));
+                            vv[u][0] = t2.x; vv[u][1] = t2.y;
+                        } else {
+                            vv[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gvo, sof, 0));
+                        }
+                    }
+            };
+            auto place = [&](int hh, const float (&vv)[NI][VW]) {
+                if (eok) {
+#pragma unroll
+                    for (int u = 0; u < NI; ++u)
+                        if (u < ni) {
+                            float *dp = gl + u * rpi * gs + hh * cp4;
+                            if constexpr (VW == 4) {
+                                st_lds2(dp, vv[u][0], vv[u][1]);
+                                st_lds2(dp + 2, vv[u][2], vv[u][3]);
+                            } else if constexpr (VW == 2) {
+                                st_lds2(dp, vv[u][0], vv[u][1]);
+                            } else {
+                                *dp = vv[u][0];
+                            }
+                        }
+                }
+            };
+            if (P.dbg & 4) {
+            } else if constexpr (CT == 1) {                       // both heads in flight: 32 registers
+                float va[NI][VW], vb[NI][VW];
+                if (nh > 0) stage(0, va);
+                if (nh > 1) stage(1, vb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (nh > 0) place(0, va);
+                if (nh > 1) place(1, vb);
+            } else {                                              // a head at a time
+                float va[NI][VW];
+                for (int hh = 0; hh < nh; ++hh) {
+                    stage(hh, va);
+                    place(hh, va);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // the loads the products and the edge pass wait for later, issued once the staging registers
+        // of grad_out are free: weight fragments, the second head's Z tile, the wave's own Z rows
+        f4 z4[8];
+        {
+            const int vo = pok ? ((wv * 8 + g) * HF + p * 4) * 4 : kOob;
+#pragma unroll
+            for (int h = 0; h < 8; ++h)
+                z4[h] = h < A.H ? __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(zrs, vo, h * A.Fp * 4, 0))
+                                : zero4();
+        }
+        if (!(P.dbg & 32)) load_wq(P.w, C, F, nk4);
+        float zn[16];
+        if (nh > 1 && !(P.dbg & 32)) load_zb(1, zn);
+        __builtin_amdgcn_sched_barrier(0);
+        // 2. d_W += g^T Z with the column sums of g on the A operands (needs no weights: runs while
+        //    they arrive);  3. q tile of the wave's heads -> LDS
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            if (hh < nh) {                                        // wave-uniform
+                const int h = h0 + hh;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (P.dbg & 2) break;
+                    const int c = ct * 32 + l;
+                    const float *gp = gtw + half * gs + hh * cp4 + min(c, C - 1);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        float a = gp[2 * s * gs];
+                        a = c < C ? a : 0.f;
+                        gsa[hh][ct] += a;
+                        dw[hh][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hh == 0 ? zb[s] : zn[s], dw[hh][ct], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                // operands of one product at a time in registers
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                const float *ap = gtw + l * gs + hh * cp4 + 2 * half;
+#pragma unroll
+                for (int t = 0; t < K4; ++t) {                    // branch-free: quads past C against zero weights
+                    if (P.dbg & 1) break;
+                    const f2 a2 = *reinterpret_cast<const f2 *>(ap + 4 * min(t, nk4 - 1));
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, wq[hh][2 * t], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, wq[hh][2 * t + 1], d, 0, 0, 0);
+                }
+                if (l < A.Fp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rb = (r & 3) + 8 * (r >> 2);
+                        (qt + rb * zs)[4 * half * zs + h * A.Fp + l] = d[r];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        lds_barrier();                                            // the q tile is whole
+        // 4. the edge pass of the wave's 8 rows (inagg_bwdg_kernel's, q from LDS)
+        const TileMeta M = N1;
+        meta_row(tile + gridDim.x, N1);                           // in flight across the edge pass
+        const int beg = M.beg, end = M.end;
+        f4 q4[8];
+        float sv[8];
+        const float *qr = qt + (wv * 8 + g) * zs + p * 4;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            q4[h] = (pok && h < A.H) ? ldv4(qr + h * A.Fp) : zero4();
+            f2 d = {0.f, 0.f};
+            pk_dot4(d, q4[h], z4[h]);
+            sv[h] = d.x + d.y;
+        }
+        const float S = heads_sum_e<3, 3>(sv, lane);
+        const float lse_i = M.lse;
+        const float adi = M.adi;
+        float dad = 0.f;
+        const int nmax = (P.dbg & 8) ? 0 : __builtin_amdgcn_readfirstlane(groups_max_i(end - beg));
+        for (int c = 0; c < nmax; c += 8) {
+            const int n = min(max(end - beg - c, 0), 8);
+            const int nw = min(nmax - c, 8);
+            int cj = M.cj, kb = M.kb;
+            if (c > 0) {                                          // wave-uniform
+                const int el = beg + c + min(p, max(n - 1, 0));
+                cj = n > 0 ? A.col[el] : 0;
+                kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+            }
+            for (int e0 = 0; e0 < nw; e0 += kBwdgE) {             // kBwdgE rows in flight
+                f4 v[kBwdgE];
+                float as[kBwdgE];
+                unsigned sb[kBwdgE];
+#pragma unroll
+                for (int e = 0; e < kBwdgE; ++e)
+                    if (e0 + e < nw) {                            // wave-uniform
+                        const int src = (lane & 56) | min(e0 + e, max(n - 1, 0));
+                        const int j = __shfl(cj, src, 64);
+                        sb[e] = (unsigned)__shfl(kb, src, 64);
+                        v[e] = *reinterpret_cast<const f4 *>(xsb + (size_t)j * row_bytes + offp);
+                        as[e] = A.xs[(size_t)j * A.Fs + A.Fp + hl];
+                    }
+#pragma unroll
+                for (int e = 0; e < kBwdgE; ++e)
+                    if (e0 + e < nw) {
+                        const float uu = as[e] + adi;
+                        const float slope = uu > 0.f ? 1.0f : A.neg_slope;
+                        const float alpha = (e0 + e < n && hlok) ? exp_fast(uu * slope - lse_i) : 0.f;
+                        const float at = (sb[e] & hbit) ? alpha * A.inv_keep : 0.f;
+                        float dv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            f2 d = {0.f, 0.f};
+                            pk_dot4(d, v[e], q4[h]);
+                            dv[h] = d.x + d.y;
+                        }
+                        const float d2 = heads_sum_e<3, 3>(dv, lane);
+                        const float du = slope * (at * d2 - alpha * S);
+                        dad += du;
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) pk_fma4(ys[h], bcast_head<3>(du, h), v[e]);
+                    }
+            }
+        }
+        meta_cols(N1);                                            // in flight across the next tile's products
+        {   // d_wd[h][f] += sum over the wave's 8 rows of (the row's sum of d_u)[h] * x_i[f]: two
+            // 16x16x4 steps per 16 columns, A[m = head][k = row] through the wave's LDS corner
+            dtw[g * 8 + hl_raw] = dad;                            // lane (g, p) owns head bitrev(p) of row g
+            __builtin_amdgcn_wave_barrier();
+            const int l16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (P.dbg & 16) break;
+                const int rl = 4 * s + k4;
+                const float av = l16 < 8 ? dtw[rl * 8 + l16] : 0.f;
+                const int rr = row0 + wv * 8 + rl;
+                const float *xr = A.xs + (size_t)(min(rr, P.N - 1) + A.dst_off) * A.Fs;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int f = 16 * nt + l16;
+                    if (16 * nt < A.Fp) {                         // wave-uniform
+                        float bv = xr[min(f, A.Fp - 1)];
+                        bv = (rr < P.N && f < A.Fp) ? bv : 0.f;
+                        ydm[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, ydm[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        lds_barrier();                                            // before the next tile's q stores
+    }
+    const int C = P.C;
+    // the block's partial sums: d_ws | d_wd rows (8 groups, then 4 waves through LDS), its d_W slab, g sums
+    float *red = fuse_lds;                                        // [2][4][256], over the q tile
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ys[h][k] = high_lanes_reduce<1, 3>(ys[h][k]);
+        if (g == 0) stv4(red + (0 * 4 + wv) * 256 + h * 32 + p * 4, ys[h]);
+    }
+    if (lane < 32) {                                              // D[m = 4 (lane / 16) + r][n = lane % 16]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(1 * 4 + wv) * 256 + (4 * (lane >> 4) + r) * 32 + 16 * nt + (lane & 15)] = ydm[nt][r];
+    }
+    __syncthreads();
+    float *dst = A.part_y + (size_t)blockIdx.x * 2 * HF;
+    for (int idx = threadIdx.x; idx < 2 * 256; idx += 256) {
+        const int which = idx >> 8, r = idx & 255, hh = r >> 5, ff = r & 31;
+        if (hh < A.H && ff < A.Fp) {
+            const float *src = red + which * 4 * 256 + r;
+            dst[which * HF + hh * A.Fp + ff] = (src[0] + src[256]) + (src[512] + src[768]);
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+        if (hh < nh) {
+            const int h = h0 + hh;
+            float *sl = P.slab + ((size_t)blockIdx.x * A.H + h) * C * P.F;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < C && l < P.F) sl[(size_t)c * P.F + l] = dw[hh][ct][r];
+                }
+                if (P.gsum) {
+                    const float tot = gsa[hh][ct] + __shfl_xor(gsa[hh][ct], 32, 64);
+                    const int c = ct * 32 + l;
+                    if (half == 0 && c < C) P.gsum[((size_t)h * gridDim.x + blockIdx.x) * C + c] = tot;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------
 struct InGeo {
@@ -2512,6 +3145,102 @@ static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
         hipLaunchKernelGGL((inagg_fwde_kernel<LRL, HPL, UF>), dim3(grid), dim3(256), 0, st, A);
     else
         hipLaunchKernelGGL((inagg_bwde_kernel<LRL, HPL, UB>), dim3(grid), dim3(256), 0, st, A);
+}
+
+// The fused tiles (inagg_fwdgf / inagg_bwdgf): where the row-per-group kernels run, every row is
+// one work item in row order (no row cut into segments) and a head's channels fit two 32-wide
+// MFMA tiles.  GATMI_FUSED=0: the separate kernels (A/B runs, the tests of the fallbacks); 1 / 2:
+// only the forward / the backward fused.
+constexpr int kFuseMaxC = 64;
+static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr, int C, bool bf16_rows, int pass) {
+    // GATMI_FUSED: bit 0 the forward, bit 1 the backward (they do not depend on each other).  The
+    // backward is off by default: measured slower than the separate kernels
+    if ((option("GATMI_FUSED", 1) & pass) == 0 || bf16_rows || C > kFuseMaxC) return false;
+    if (gr->plan.n_split_rows != 0 || gr->plan.n_items != gr->num_dst) return false;
+    return group_rows(g, A);
+}
+struct FusePlan {
+    int grid, grid_fwd, ct, vw;
+    size_t lds_fwd, lds_bwd;
+    FuseArgs P;
+};
+static FusePlan fuse_plan(const InGeo &g, int N, int H, int C, int F) {
+    FusePlan f{};
+    f.P.C = C;
+    f.P.F = F;
+    f.P.N = N;
+    f.P.ntiles = (N + 31) / 32;
+    f.P.dbg = option("GATMI_FUSE_DBG", 0);
+    f.P.zs = g.HF + 2;                       // forward (the backward sets its own): 2 mod 4
+    f.P.cp4 = round_up4(C);
+    f.P.gs = 2 * f.P.cp4 + 2;                // 2 mod 4
+    f.ct = (C + 31) / 32;
+    f.vw = C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);
+    f.lds_fwd = (size_t)32 * (f.P.zs > H * C ? f.P.zs : H * C) * 4;   // the Z tile, then the out tile over it
+    f.lds_bwd = ((size_t)32 * (g.HF + 4) + (size_t)4 * 32 * f.P.gs + 4 * 64) * 4;   // q tile | g tiles | d_u sums
+    if (f.lds_bwd < 2 * 4 * 256 * 4) f.lds_bwd = 2 * 4 * 256 * 4;   // the closing sums of the block
+    // two blocks per CU are resident in the backward (three in the forward); a block walks its
+    // tiles with barriers, so blocks beyond the resident ones only add tails
+    const int want = device_cus() * 2;
+    int grid = f.P.ntiles < want ? f.P.ntiles : want;
+    if (grid < 8) grid = 8;
+    f.grid = (grid + 7) / 8 * 8;
+    const int want3 = device_cus() * 3;
+    grid = f.P.ntiles < want3 ? f.P.ntiles : want3;
+    if (grid < 8) grid = 8;
+    f.grid_fwd = (grid + 7) / 8 * 8;
+    return f;
+}
+template <class K> static int grant_lds(K kern, size_t lds, size_t *granted) {
+    if (*granted < lds) {
+        GATMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        *granted = lds;
+    }
+    return GATMI_OK;
+}
+static int fused_fwd_launch(const FusePlan &f, const InArgs &A, float *wimg, hipStream_t st) {
+    const int dev = device_index();
+    static size_t granted[2][kMaxDevices] = {};
+    FuseArgs P = f.P;
+    {
+        const int tot = A.H * A.Fp * f.ct * 32;
+        hipLaunchKernelGGL(inagg_wimg_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, P.w, A.H, P.C, P.F, A.Fp,
+                           f.ct * 32, wimg);
+        GATMI_HIP(hipGetLastError());
+        P.wimg = wimg;
+    }
+    if (f.ct == 1) {
+        if (int e = grant_lds(inagg_fwdgf_kernel<1>, f.lds_fwd, &granted[0][dev])) return e;
+        hipLaunchKernelGGL(inagg_fwdgf_kernel<1>, dim3(f.grid_fwd), dim3(256), f.lds_fwd, st, A, P);
+    } else {
+        if (int e = grant_lds(inagg_fwdgf_kernel<2>, f.lds_fwd, &granted[1][dev])) return e;
+        hipLaunchKernelGGL(inagg_fwdgf_kernel<2>, dim3(f.grid_fwd), dim3(256), f.lds_fwd, st, A, P);
+    }
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+template <int CT, int VW>
+static int fused_bwd_launch_t(const FusePlan &f, const InArgs &A, const FuseArgs &P, hipStream_t st) {
+    static size_t granted[kMaxDevices] = {};
+    if (int e = grant_lds(inagg_bwdgf_kernel<CT, VW>, f.lds_bwd, &granted[device_index()])) return e;
+    hipLaunchKernelGGL((inagg_bwdgf_kernel<CT, VW>), dim3(f.grid), dim3(256), f.lds_bwd, st, A, P);
+    GATMI_HIP(hipGetLastError());
+    return GATMI_OK;
+}
+static int fused_bwd_launch(const FusePlan &f, const InGeo &g, const InArgs &A, hipStream_t st) {
+    FuseArgs P = f.P;
+    P.zs = g.HF + 4;                         // the q tile is read back as float4
+    const int lpr = next_pow2(P.C / f.vw);   // lanes per row of one head's columns of grad_out
+    P.lpr_log = ilog2(lpr < 2 ? 2 : lpr);
+    if (f.ct == 1) {
+        if (f.vw == 4) return fused_bwd_launch_t<1, 4>(f, A, P, st);
+        if (f.vw == 2) return fused_bwd_launch_t<1, 2>(f, A, P, st);
+        return fused_bwd_launch_t<1, 1>(f, A, P, st);
+    }
+    if (f.vw == 4) return fused_bwd_launch_t<2, 4>(f, A, P, st);
+    if (f.vw == 2) return fused_bwd_launch_t<2, 2>(f, A, P, st);
+    return fused_bwd_launch_t<2, 1>(f, A, P, st);
 }
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
@@ -2881,6 +3610,7 @@ extern "C" size_t gatmi_inagg_fwd_workspace_bytes(const gatmi_graph *g, const ga
     cv.take<float>(slots * geo.HF);
     cv.take<int>(stream_ws_ints(g));   // chunk queue + table of the streaming kernel
     cv.take<float>((size_t)s->heads * s->channels * 4 * geo.Fp);   // block-diagonal weight of head groups
+    cv.take<float>((size_t)s->heads * geo.Fp * 64);                 // W^T image of the fused forward
     return cv.off + 256;
 }
 
@@ -2906,8 +3636,18 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
     A.part_acc = cv.take<float>(slots * geo.HF);
     int *stream_ws = cv.take<int>(stream_ws_ints(g));
     float *bdiag = cv.take<float>((size_t)H * C * 4 * geo.Fp);
+    float *wimg = cv.take<float>((size_t)H * geo.Fp * 64);    // W^T image of the fused forward
     A.z = z;
     A.lse = lse;
+    if (fused_covers(geo, A, g, C, a->xs16 != nullptr, 1)) {
+        // edge pass and out = Z W^T + bias of a 32-row tile in one kernel
+        ProfScope ps("inagg_fwd_fused", st);
+        FusePlan f = fuse_plan(geo, N, H, C, F);
+        f.P.w = a->weight;
+        f.P.bias = a->bias;
+        f.P.out = out;
+        return fused_fwd_launch(f, A, wimg, st);
+    }
     {
         ProfScope ps("inagg_fwd", st);
         // table beyond the Infinity Cache: the LDS-DMA streaming kernel (6.67 ms against 6.93 ms
@@ -2984,8 +3724,13 @@ InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &ge
     w.part_y = cv.take<float>((size_t)w.waves * 2 * geo.HF);
     w.dwsd = cv.take<float>((size_t)2 * geo.HF);
     w.nsplit = dw_plan(g->num_dst, s->heads, s->channels, s->in_features).nsplit;
-    w.slab = cv.take<float>((size_t)w.nsplit * s->heads * s->channels * s->in_features);
-    w.gsum = cv.take<float>((size_t)w.nsplit * s->heads * s->channels);
+    int slabs = w.nsplit;
+    if (s->channels <= kFuseMaxC) {        // the fused backward writes one d_W slab per block
+        const int fg = fuse_plan(geo, g->num_dst, s->heads, s->channels, s->in_features).grid;
+        if (fg > slabs) slabs = fg;
+    }
+    w.slab = cv.take<float>((size_t)slabs * s->heads * s->channels * s->in_features);
+    w.gsum = cv.take<float>((size_t)slabs * s->heads * s->channels);
     w.bdiag = cv.take<float>((size_t)s->heads * s->channels * 4 * geo.Fp);   // head groups of <= 4
     w.bytes = cv.off + 256;
     return w;
@@ -3015,6 +3760,33 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     const InBwdWs w = carve_in_bwd(g, &a->shape, geo, ws);
     InArgs A;
     fill_in_args(A, g, a, geo);
+    if (N > 0 && fused_covers(geo, A, g, C, a->xs16 != nullptr, 2)) {
+        // q = g W, the edge pass, d_W = g^T Z and the column sums of g per 32-row tile in one kernel
+        FusePlan f = fuse_plan(geo, N, H, C, F);
+        A.zin = z;
+        A.lsein = lse;
+        A.part_y = w.part_y;
+        f.P.w = a->weight;
+        f.P.gout = grad_out;
+        f.P.slab = w.slab;
+        f.P.gsum = d_bias ? w.gsum : nullptr;
+        {
+            ProfScope ps("inagg_bwd_fused", st);
+            if (int e = fused_bwd_launch(f, geo, A, st)) return e;
+        }
+        ProfScope ps("inagg_colsums", st);
+        SumJob j0{w.part_y, w.dwsd, f.grid, 2 * geo.HF, geo.HF};
+        SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, f.grid, 2 * geo.HF, geo.HF};
+        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0, j1, j1);
+        GATMI_HIP(hipGetLastError());
+        const long long tot = (long long)H * C * F;
+        const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
+        hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab, f.grid, H, C, F,
+                           geo.Fp, a->weight, a->att_src, a->att_dst, w.dwsd, w.gsum, d_weight, d_att_src,
+                           d_att_dst, d_bias);
+        GATMI_HIP(hipGetLastError());
+        return GATMI_OK;
+    }
     if (N > 0) {
         // q[:, h, :] = g[:, h, :] W_h   (padded columns written as zeros)
         ProfScope ps("inagg_q_gemm", st);
