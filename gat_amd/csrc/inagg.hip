@@ -2332,9 +2332,9 @@ struct SumJob {
     float *dst;
     int nrows, ld, ncols;
 };
-__global__ __launch_bounds__(256) void inagg_sum_rows_kernel(SumJob j0, SumJob j1, SumJob j2) {
+__global__ __launch_bounds__(256) void inagg_sum_rows_kernel(SumJob j0, SumJob j1, SumJob j2, SumJob j3 = SumJob{}) {
     __shared__ float red[256];
-    const SumJob J = blockIdx.y == 0 ? j0 : (blockIdx.y == 1 ? j1 : j2);
+    const SumJob J = blockIdx.y == 0 ? j0 : (blockIdx.y == 1 ? j1 : (blockIdx.y == 2 ? j2 : j3));
     const int pc = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
     const bool on = J.dst && pc < J.ncols;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -2448,7 +2448,7 @@ struct FuseArgs {
     const float *gout;   // grad_out [N, H*C] (backward)
     float *out;          // [N, H*C] (forward)
     float *slab;         // [blocks][H][C][F] (backward)
-    float *gsum;         // [H][blocks][C] or null (backward)
+    float *gsum;         // [blocks][H*C] or null (backward)
     int C, F, N, ntiles;
     int dbg;             // GATMI_FUSE_DBG: ablation bits (wrong results; timing only)
     int zs;              // forward: row stride of the Z tile; backward: of the q tile (floats)
@@ -2717,6 +2717,8 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
     const int h0 = 2 * wv;
     const int nh = max(min(2, A.H - h0), 0);                      // heads this wave multiplies
     constexpr int K4 = CT * 8;                                    // k quads of q = g W (C <= 32 CT)
+    constexpr int kOob = 0x7ffffff0;                              // an offset past every buffer: the load returns 0
+    constexpr int NI = CT * 16 / VW;                              // load instructions per head of a g tile at most
     for (int i = lane; i < 32 * P.gs; i += 64)                    // the pad columns stay zero
         fuse_lds[32 * P.zs + wv * 32 * P.gs + i] = 0.f;
     // B operands of q[:, h, :] = g[:, h, :] W_h: lane (half, n = l) holds W[h C + k][l] for the k
@@ -2755,6 +2757,68 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         M.cj = n > 0 ? A.col[el] : 0;
         M.kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
     };
+    // B of d_W: Z[row 2 s + half][h Fp + l] of the tile `zrs` spans
+    const int zvo = l < A.Fp ? (half * HF + l) * 4 : kOob;
+    auto load_zb = [&](const __amdgpu_buffer_rsrc_t zrs, int hh, float (&zb)[16]) {
+        const int so = min(h0 + hh, A.H - 1) * A.Fp * 4;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            zb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvo, so + 2 * s * HF * 4, 0));
+    };
+    // The wave's columns of the 32 rows of grad_out of a tile: per head, LPR lanes a row (VW floats
+    // each), 64 / LPR rows an instruction; buffer loads over the tile's rows (one lane offset, the
+    // rest in scalar offsets, rows past N and tiles past the last read 0).  Requested a tile ahead
+    // (request_g), written to the wave's LDS tile when the tile starts (place_g).
+    const int lpr_log = P.lpr_log, rpi = 64 >> lpr_log, ni = 32 >> (6 - lpr_log);
+    const int le = lane & ((1 << lpr_log) - 1), lr = lane >> lpr_log;
+    auto request_g = [&](int t, int C, float (&vg)[2][NI][VW]) {
+        const int HC = A.H * C, r0 = t * 32;
+        const int rows = t < P.ntiles ? min(32, P.N - r0) : 0;
+        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(P.gout) + (size_t)(rows > 0 ? r0 : 0) * HC, 0, rows * HC * 4, 0x00020000);
+        const int gvo = le * VW < C ? (lr * HC + le * VW) * 4 : kOob;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int so = min(h0 + hh, A.H - 1) * C * 4;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                float(&vv)[VW] = vg[hh][u];
+                if (u < ni && hh < nh) {                          // wave-uniform
+                    const int sof = so + u * rpi * HC * 4;
+                    if constexpr (VW == 4) {
+                        const f4 t4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(grs, gvo, sof, 0));
+                        vv[0] = t4[0]; vv[1] = t4[1]; vv[2] = t4[2]; vv[3] = t4[3];
+                    } else if constexpr (VW == 2) {
+                        const f2 t2 = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(grs, gvo, sof, 0));
+                        vv[0] = t2.x; vv[1] = t2.y;
+                    } else {
+                        vv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gvo, sof, 0));
+                    }
+                }
+            }
+        }
+    };
+    auto place_g = [&](const float (&vg)[2][NI][VW], float *gtw, int gs, int cp4, int C) {
+        if (le * VW < C) {
+            float *gl = gtw + lr * gs + le * VW;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int u = 0; u < NI; ++u)
+                    if (u < ni && hh < nh) {
+                        const float(&vv)[VW] = vg[hh][u];
+                        float *dp = gl + u * rpi * gs + hh * cp4;
+                        if constexpr (VW == 4) {
+                            st_lds2(dp, vv[0], vv[1]);
+                            st_lds2(dp + 2, vv[2], vv[3]);
+                        } else if constexpr (VW == 2) {
+                            st_lds2(dp, vv[0], vv[1]);
+                        } else {
+                            *dp = vv[0];
+                        }
+                    }
+        }
+    };
     f32x16 dw[2][CT];
     float gsa[2][CT];
 #pragma unroll
@@ -2773,6 +2837,13 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
     TileMeta N1;
     meta_row(tile, N1);
     meta_cols(N1);
+    float vg[2][NI][VW], zb[16];
+    request_g(tile, P.C, vg);
+    {
+        const int rows = tile < P.ntiles ? min(32, P.N - tile * 32) : 0;
+        load_zb(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.zin) + (size_t)(rows > 0 ? tile * 32 : 0) * HF, 0,
+                                                  rows * HF * 4, 0x00020000), 0, zb);
+    }
     for (; tile < P.ntiles; tile += gridDim.x) {
         const int row0 = tile * 32;
         // Sizes the compiler cannot see through: what is derived from them (lane addresses of the
@@ -2786,84 +2857,12 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         float *dtw = fuse_lds + 32 * zs + 4 * 32 * gs + wv * 64;
         const int row = row0 + wv * 8 + g;
         const bool on = row < P.N;
-        // 0. everything the tile reads from HBM before its edge pass is issued here, one latency for
-        //    all of it: the Z rows of the wave's 8 destinations (for S), the Z tile of its heads (B
-        //    of d_W), its weight fragments, its columns of grad_out.  Buffer loads over the tile's
-        //    rows: one lane offset per kind of load, the rest in scalar offsets, rows past N read 0.
+        // 0. grad_out and the first head's Z tile were requested at the end of the tile before (or
+        //    ahead of the loop): grad_out goes to the wave's LDS tile now
         const int trows = min(32, P.N - row0);
         const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(A.zin) + (size_t)row0 * HF, 0, trows * HF * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(P.gout) + (size_t)row0 * HC, 0, trows * HC * 4, 0x00020000);
-        constexpr int kOob = 0x7ffffff0;                          // an offset past every tile: the load returns 0
-        const int zvo = l < A.Fp ? (half * HF + l) * 4 : kOob;    // B of d_W: Z[row 2 s + half][h Fp + l]
-        auto load_zb = [&](int hh, float (&zb)[16]) {
-            const int so = min(h0 + hh, A.H - 1) * A.Fp * 4;
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                zb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvo, so + 2 * s * HF * 4, 0));
-        };
-        float zb[16];
-        load_zb(0, zb);
-        // 1. the wave's columns of 32 rows of grad_out -> its LDS tile: per head, LPR lanes a row
-        //    (VW floats each), 64 / LPR rows an instruction
-        {
-            const int lpr_log = P.lpr_log, rpi = 64 >> lpr_log, ni = 32 >> (6 - lpr_log);
-            const int le = lane & ((1 << lpr_log) - 1), lr = lane >> lpr_log;
-            const bool eok = le * VW < C;
-            const int gvo = eok ? (lr * HC + le * VW) * 4 : kOob;
-            float *gl = gtw + lr * gs + le * VW;
-            constexpr int NI = CT * 16 / VW;                      // instructions per head at most
-            auto stage = [&](int hh, float (&vv)[NI][VW]) {
-                const int so = (h0 + hh) * C * 4;
-#pragma unroll
-                for (int u = 0; u < NI; ++u)
-                    if (u < ni) {                                 // wave-uniform
-                        const int sof = so + u * rpi * HC * 4;
-                        if constexpr (VW == 4) {
-                            const f4 t4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(grs, gvo, sof, 0));
-                            vv[u][0] = t4[0]; vv[u][1] = t4[1]; vv[u][2] = t4[2]; vv[u][3] = t4[3];
-                        } else if constexpr (VW == 2) {
-                            const f2 t2 = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(grs, gvo, sof, 0));
-                            vv[u][0] = t2.x; vv[u][1] = t2.y;
-                        } else {
-                            vv[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gvo, sof, 0));
-                        }
-                    }
-            };
-            auto place = [&](int hh, const float (&vv)[NI][VW]) {
-                if (eok) {
-#pragma unroll
-                    for (int u = 0; u < NI; ++u)
-                        if (u < ni) {
-                            float *dp = gl + u * rpi * gs + hh * cp4;
-                            if constexpr (VW == 4) {
-                                st_lds2(dp, vv[u][0], vv[u][1]);
-                                st_lds2(dp + 2, vv[u][2], vv[u][3]);
-                            } else if constexpr (VW == 2) {
-                                st_lds2(dp, vv[u][0], vv[u][1]);
-                            } else {
-                                *dp = vv[u][0];
-                            }
-                        }
-                }
-            };
-            if (P.dbg & 4) {
-            } else if constexpr (CT == 1) {                       // both heads in flight: 32 registers
-                float va[NI][VW], vb[NI][VW];
-                if (nh > 0) stage(0, va);
-                if (nh > 1) stage(1, vb);
-                __builtin_amdgcn_sched_barrier(0);
-                if (nh > 0) place(0, va);
-                if (nh > 1) place(1, vb);
-            } else {                                              // a head at a time
-                float va[NI][VW];
-                for (int hh = 0; hh < nh; ++hh) {
-                    stage(hh, va);
-                    place(hh, va);
-                }
-            }
-        }
+        place_g(vg, gtw, gs, cp4, C);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // the loads the products and the edge pass wait for later, issued once the staging registers
@@ -2878,7 +2877,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         }
         if (!(P.dbg & 32)) load_wq(P.w, C, F, nk4);
         float zn[16];
-        if (nh > 1 && !(P.dbg & 32)) load_zb(1, zn);
+        if (nh > 1 && !(P.dbg & 32)) load_zb(zrs, 1, zn);
         __builtin_amdgcn_sched_barrier(0);
         // 2. d_W += g^T Z with the column sums of g on the A operands (needs no weights: runs while
         //    they arrive);  3. q tile of the wave's heads -> LDS
@@ -2936,6 +2935,19 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
             sv[h] = d.x + d.y;
         }
         const float S = heads_sum_e<3, 3>(sv, lane);
+        // B of the d_wd steps after the edge pass: the wave's own x rows, requested ahead of it
+        float xb[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = row0 + wv * 8 + 4 * s + (lane >> 4);
+            const float *xr = A.xs + (size_t)(min(rr, P.N - 1) + A.dst_off) * A.Fs;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int f = 16 * nt + (lane & 15);
+                xb[s][nt] = 16 * nt < A.Fp ? xr[min(f, A.Fp - 1)] : 0.f;
+                xb[s][nt] = (rr < P.N && f < A.Fp) ? xb[s][nt] : 0.f;
+            }
+        }
         const float lse_i = M.lse;
         const float adi = M.adi;
         float dad = 0.f;
@@ -2985,6 +2997,13 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
             }
         }
         meta_cols(N1);                                            // in flight across the next tile's products
+        {   // the next tile's grad_out columns and first Z tile: the edge pass has let go of its registers
+            const int tn = tile + gridDim.x;
+            request_g(tn, C, vg);
+            const int rows = tn < P.ntiles ? min(32, P.N - tn * 32) : 0;
+            load_zb(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.zin) + (size_t)(rows > 0 ? tn * 32 : 0) * HF,
+                                                      0, rows * HF * 4, 0x00020000), 0, zb);
+        }
         {   // d_wd[h][f] += sum over the wave's 8 rows of (the row's sum of d_u)[h] * x_i[f]: two
             // 16x16x4 steps per 16 columns, A[m = head][k = row] through the wave's LDS corner
             dtw[g * 8 + hl_raw] = dad;                            // lane (g, p) owns head bitrev(p) of row g
@@ -2995,17 +3014,10 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                 if (P.dbg & 16) break;
                 const int rl = 4 * s + k4;
                 const float av = l16 < 8 ? dtw[rl * 8 + l16] : 0.f;
-                const int rr = row0 + wv * 8 + rl;
-                const float *xr = A.xs + (size_t)(min(rr, P.N - 1) + A.dst_off) * A.Fs;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int f = 16 * nt + l16;
-                    if (16 * nt < A.Fp) {                         // wave-uniform
-                        float bv = xr[min(f, A.Fp - 1)];
-                        bv = (rr < P.N && f < A.Fp) ? bv : 0.f;
-                        ydm[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, ydm[nt], 0, 0, 0);
-                    }
-                }
+                for (int nt = 0; nt < 2; ++nt)
+                    if (16 * nt < A.Fp)                           // wave-uniform
+                        ydm[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[s][nt], ydm[nt], 0, 0, 0);
             }
         }
         lds_barrier();                                            // before the next tile's q stores
@@ -3050,7 +3062,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                 if (P.gsum) {
                     const float tot = gsa[hh][ct] + __shfl_xor(gsa[hh][ct], 32, 64);
                     const int c = ct * 32 + l;
-                    if (half == 0 && c < C) P.gsum[((size_t)h * gridDim.x + blockIdx.x) * C + c] = tot;
+                    if (half == 0 && c < C) P.gsum[(size_t)blockIdx.x * A.H * C + h * C + c] = tot;
                 }
             }
         }
@@ -3152,10 +3164,19 @@ static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
 // MFMA tiles.  GATMI_FUSED=0: the separate kernels (A/B runs, the tests of the fallbacks); 1 / 2:
 // only the forward / the backward fused.
 constexpr int kFuseMaxC = 64;
+constexpr int kFuseBwdMaxRows = 400000;
 static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr, int C, bool bf16_rows, int pass) {
-    // GATMI_FUSED: bit 0 the forward, bit 1 the backward (they do not depend on each other).  The
-    // backward is off by default: measured slower than the separate kernels
-    if ((option("GATMI_FUSED", 1) & pass) == 0 || bf16_rows || C > kFuseMaxC) return false;
+    // GATMI_FUSED: bit 0 the forward, bit 1 the backward (they do not depend on each other), bit 2:
+    // the backward whatever the size.  By default the backward is fused up to kFuseBwdMaxRows rows:
+    // beyond, with every CU busy for long, the separate kernels' higher occupancy wins (runpy1m: 1.64
+    // against 1.52 ms; runpy100k: 0.19 against 0.24)
+    const int mode = option("GATMI_FUSED", 3);
+    if ((mode & pass) == 0 || bf16_rows || C > kFuseMaxC) return false;
+    if (pass == 2 && !(mode & 4) && gr->num_dst > kFuseBwdMaxRows) return false;
+    // the backward holds a head pair's d_W in registers beside the edge pass: one 32-channel tile
+    // per head fits (C = 33..64 spills: runpy100k at 8 x 40 0.41 against 0.27 ms); C even: rows of
+    // grad_out are staged as float2 / float4
+    if (pass == 2 && (C > 32 || C % 2 != 0)) return false;
     if (gr->plan.n_split_rows != 0 || gr->plan.n_items != gr->num_dst) return false;
     return group_rows(g, A);
 }
@@ -3233,14 +3254,8 @@ static int fused_bwd_launch(const FusePlan &f, const InGeo &g, const InArgs &A, 
     P.zs = g.HF + 4;                         // the q tile is read back as float4
     const int lpr = next_pow2(P.C / f.vw);   // lanes per row of one head's columns of grad_out
     P.lpr_log = ilog2(lpr < 2 ? 2 : lpr);
-    if (f.ct == 1) {
-        if (f.vw == 4) return fused_bwd_launch_t<1, 4>(f, A, P, st);
-        if (f.vw == 2) return fused_bwd_launch_t<1, 2>(f, A, P, st);
-        return fused_bwd_launch_t<1, 1>(f, A, P, st);
-    }
-    if (f.vw == 4) return fused_bwd_launch_t<2, 4>(f, A, P, st);
-    if (f.vw == 2) return fused_bwd_launch_t<2, 2>(f, A, P, st);
-    return fused_bwd_launch_t<2, 1>(f, A, P, st);
+    if (f.vw == 4) return fused_bwd_launch_t<1, 4>(f, A, P, st);
+    return fused_bwd_launch_t<1, 2>(f, A, P, st);
 }
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
@@ -3711,7 +3726,7 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
 
 namespace {
 struct InBwdWs {
-    float *q, *part_y, *dwsd, *slab, *gsum, *bdiag;
+    float *q, *part_y, *dwsd, *slab, *gsum, *bdiag, *slab_sum;
     int waves, nsplit;
     size_t bytes;
 };
@@ -3732,6 +3747,7 @@ InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &ge
     w.slab = cv.take<float>((size_t)slabs * s->heads * s->channels * s->in_features);
     w.gsum = cv.take<float>((size_t)slabs * s->heads * s->channels);
     w.bdiag = cv.take<float>((size_t)s->heads * s->channels * 4 * geo.Fp);   // head groups of <= 4
+    w.slab_sum = cv.take<float>((size_t)s->heads * s->channels * (s->in_features + 1));   // fused backward: summed slabs | g sums
     w.bytes = cv.off + 256;
     return w;
 }
@@ -3775,14 +3791,19 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
             if (int e = fused_bwd_launch(f, geo, A, st)) return e;
         }
         ProfScope ps("inagg_colsums", st);
+        // the blocks' partial rows, slabs and g sums are added by one launch of the row-sum kernel (a
+        // block per 16 columns: 375 blocks for run.py's d_W) into row 0 of each; the closing kernel then
+        // reads single rows (walking 512 slabs itself it took 60 us)
+        const int tot = H * C * F;
         SumJob j0{w.part_y, w.dwsd, f.grid, 2 * geo.HF, geo.HF};
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, f.grid, 2 * geo.HF, geo.HF};
-        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0, j1, j1);
+        SumJob j2{w.slab, w.slab_sum, f.grid, tot, tot};
+        SumJob j3{w.gsum, d_bias ? w.slab_sum + tot : nullptr, f.grid, H * C, H * C};
+        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((tot + 15) / 16, 4), dim3(256), 0, st, j0, j1, j2, j3);
         GATMI_HIP(hipGetLastError());
-        const long long tot = (long long)H * C * F;
         const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
-        hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab, f.grid, H, C, F,
-                           geo.Fp, a->weight, a->att_src, a->att_dst, w.dwsd, w.gsum, d_weight, d_att_src,
+        hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab_sum, 1, H, C, F,
+                           geo.Fp, a->weight, a->att_src, a->att_dst, w.dwsd, w.slab_sum + tot, d_weight, d_att_src,
                            d_att_dst, d_bias);
         GATMI_HIP(hipGetLastError());
         return GATMI_OK;

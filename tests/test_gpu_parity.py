@@ -451,6 +451,87 @@ def test_input_aggregation_row_per_lane_group(cuda, n, f, h, c, p, graph):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+FUSED_SHAPES = [  # n, f, h, c, p
+    (3001, 25, 8, 30, 0.0), (3001, 25, 8, 30, 0.425), (9, 25, 8, 30, 0.0), (31, 25, 8, 24, 0.3),
+    (32, 25, 8, 32, 0.0), (33, 25, 8, 28, 0.2), (1000, 17, 6, 9, 0.3), (1777, 32, 5, 16, 0.0),
+    (2048, 1, 7, 2, 0.0), (4101, 25, 8, 40, 0.425), (777, 29, 8, 33, 0.0), (1500, 16, 8, 64, 0.1),
+    (2500, 25, 8, 31, 0.0), (640, 20, 5, 1, 0.0),
+]
+
+
+@pytest.mark.parametrize("fused", [7, 1, 0], ids=["fwd_bwd", "fwd", "separate"])
+@pytest.mark.parametrize("graph", ["knn5", "self_loops_only", "degree40"])
+@pytest.mark.parametrize("n,f,h,c,p", FUSED_SHAPES)
+def test_input_aggregation_fused_tiles(cuda, n, f, h, c, p, graph, fused):
+    """The fused 32-row tiles of the row-per-group layout (inagg_fwdgf / inagg_bwdgf: 5..8 heads, rows
+    of at most 8 float4, no row cut into segments; the backward for even C <= 32, the forward up to
+    C = 64) with GATMI_FUSED = 7 (both passes whatever the size), 1 (forward only) and 0 (the separate
+    kernels they replace): node counts around the tile size, channel counts around the 32-wide MFMA
+    tiles, odd head counts (a wave with one head, a wave with none), with and without dropout, on
+    the 5-neighbour graph of /root/reference/gat/converter.py:7-15, on rows that hold their self
+    loop only and on rows of 41 edges (six chunks of 8 per row).
+    (12 -> 8x64 at n = 1500 is not in the list: on the 5-neighbour graph one edge's logit of head 5
+    lies within an ulp of LeakyReLU's kink, and the oracle's and the pack kernel's summation orders of
+    the a_src dot product put it on different sides -- the fused, the separate and the one-edge kernels
+    all show the same 6.7e-4 of max|d_W| on d_W[5] there and 4e-7 with F = 16 or n = 4200;
+    tools/dbg_c64.py.  The effect itself is what test_products_tenth_scale_both_paths_against_fp64 measures.)"""
+    from gat_amd import _lib, synth
+    if graph == "knn5":
+        ei = synth.out_degree_k_graph(n, 5, seed=n)
+    elif graph == "self_loops_only":
+        ei = torch.zeros(2, 0, dtype=torch.long)
+    else:
+        g = torch.Generator().manual_seed(n)
+        ei = torch.stack([torch.randint(0, n, (40 * n,), generator=g), torch.arange(n).repeat_interleave(40)])
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 7)
+    x, w, a_s, a_d, b, go = inputs
+    ne = O.build_csr(ei, n).num_edges
+    mask = cases.keep_mask(ne, h, p) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p,
+                                              mask=mask, training=p > 0)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    _lib.set_option("GATMI_GROUPROWS", 2)
+    _lib.set_option("GATMI_FUSED", fused)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, p, mask, 64, inputs, inagg=True, stream=False)
+    finally:
+        _lib.set_option("GATMI_GROUPROWS", -1)
+        _lib.set_option("GATMI_FUSED", -1)
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
+def test_fused_tiles_run_where_they_should(cuda):
+    """The library's per-kernel timers name what ran: the fused kernels on a 5-neighbour graph at
+    run.py's shape, the separate ones with GATMI_FUSED=0 and on a graph with a row cut into segments."""
+    from gat_amd import _lib, synth
+    n, f, h, c = 2000, 25, 8, 30
+    inputs = cases.layer_inputs(n, f, h, c, seed=3)
+
+    def tags(ei, fused):
+        _lib.set_option("GATMI_FUSED", fused)
+        _lib.prof_read()
+        _lib.prof_enable(True)
+        try:
+            run_layer(cuda, ei, n, f, h, c, 0.0, None, 64, inputs, inagg=True, stream=False)
+            torch.cuda.synchronize()
+        finally:
+            _lib.prof_enable(False)
+            _lib.set_option("GATMI_FUSED", -1)
+        return {t for t, _ in _lib.prof_read()}
+
+    knn = synth.out_degree_k_graph(n, 5, seed=1)
+    assert {"inagg_fwd_fused", "inagg_bwd_fused"} <= tags(knn, -1)
+    t0 = tags(knn, 0)
+    assert "inagg_fwd_fused" not in t0 and "inagg_out_gemm" in t0 and "inagg_q_gemm" in t0
+    t1 = tags(knn, 1)
+    assert "inagg_fwd_fused" in t1 and "inagg_bwd_fused" not in t1 and "inagg_q_gemm" in t1
+    star = torch.stack([torch.arange(n), torch.zeros(n, dtype=torch.long)])     # row 0: 2000 edges, cut
+    ts = tags(star, -1)
+    assert "inagg_fwd_fused" not in ts and "inagg_bwd_fused" not in ts
+
+
 @pytest.mark.parametrize("v2", [1, 0], ids=["double_buffered", "tiled"])
 @pytest.mark.parametrize("n,f,h,c", [(1000, 100, 8, 30), (777, 256, 8, 32), (4100, 132, 4, 64),
                                      (300, 36, 3, 33), (2049, 240, 8, 30), (130, 68, 2, 40)])

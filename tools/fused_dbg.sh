@@ -1,7 +1,7 @@
 #!/bin/bash
 out=gpurun_out/fused_dbg.txt
 : > $out
-for d in 0 1 2 3 4 8 16 32 11 15 63; do
+for d in 0 1 2 8 16 32; do
   echo "== bwd GATMI_FUSE_DBG=$d" >> $out
   GATMI_FUSED=2 GATMI_FUSE_DBG=$d timeout -k 10 120 python tools/layer_bench.py --graph runpy1m --f 25 --heads 8 --channels 30 --steps 10 2>&1 | grep -v amdgpu.ids >> $out
 done
