@@ -2441,6 +2441,12 @@ __global__ __launch_bounds__(256) void inagg_finalize_kernel(
 // used as two MFMA steps (the K order of a product is free as long as A and B agree) -- with a
 // row stride of 2 mod 4 floats: 32 rows x 2 banks cover the 64 banks once.
 // ---------------------------------------------------------------------------------
+#ifndef GATMI_BWDGF_E   // gathered rows in flight per lane group of the fused backward: 4 / 8 spill (1.95 / 2.11 against 1.64 ms at 10^6 rows)
+#define GATMI_BWDGF_E 2
+#endif
+#ifndef GATMI_FWDGF_OCC  // blocks per CU the fused forward (C <= 32) is compiled for: 4 (128 registers) 0.89 ms at 10^6 rows, 3: 0.97
+#define GATMI_FWDGF_OCC 4
+#endif
 struct FuseArgs {
     const float *w;      // [H*C, F]
     const float *wimg;   // forward: [H][Fp][32 CT] = W^T per head, zero padded (inagg_wimg_kernel)
@@ -2486,7 +2492,7 @@ __global__ void inagg_wimg_kernel(const float *w, int H, int C, int F, int Fp, i
 }
 
 template <int CT>
-__global__ __launch_bounds__(256, 3) void inagg_fwdgf_kernel(const InArgs A, const FuseArgs P) {
+__global__ __launch_bounds__(256, CT == 1 ? GATMI_FWDGF_OCC : 3) void inagg_fwdgf_kernel(const InArgs A, const FuseArgs P) {
     extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
     float *zt = fuse_lds;                                         // [32 rows][zs]
     const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
@@ -2717,6 +2723,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
     const int h0 = 2 * wv;
     const int nh = max(min(2, A.H - h0), 0);                      // heads this wave multiplies
     constexpr int K4 = CT * 8;                                    // k quads of q = g W (C <= 32 CT)
+    constexpr int kE = GATMI_BWDGF_E;                             // gathered rows in flight per lane group
     constexpr int kOob = 0x7ffffff0;                              // an offset past every buffer: the load returns 0
     constexpr int NI = CT * 16 / VW;                              // load instructions per head of a g tile at most
     for (int i = lane; i < 32 * P.gs; i += 64)                    // the pad columns stay zero
@@ -2961,12 +2968,12 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                 cj = n > 0 ? A.col[el] : 0;
                 kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
             }
-            for (int e0 = 0; e0 < nw; e0 += kBwdgE) {             // kBwdgE rows in flight
-                f4 v[kBwdgE];
-                float as[kBwdgE];
-                unsigned sb[kBwdgE];
+            for (int e0 = 0; e0 < nw; e0 += kE) {             // a whole chunk of rows in flight: one latency per chunk
+                f4 v[kE];
+                float as[kE];
+                unsigned sb[kE];
 #pragma unroll
-                for (int e = 0; e < kBwdgE; ++e)
+                for (int e = 0; e < kE; ++e)
                     if (e0 + e < nw) {                            // wave-uniform
                         const int src = (lane & 56) | min(e0 + e, max(n - 1, 0));
                         const int j = __shfl(cj, src, 64);
@@ -2975,7 +2982,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                         as[e] = A.xs[(size_t)j * A.Fs + A.Fp + hl];
                     }
 #pragma unroll
-                for (int e = 0; e < kBwdgE; ++e)
+                for (int e = 0; e < kE; ++e)
                     if (e0 + e < nw) {
                         const float uu = as[e] + adi;
                         const float slope = uu > 0.f ? 1.0f : A.neg_slope;
@@ -3206,7 +3213,7 @@ static FusePlan fuse_plan(const InGeo &g, int N, int H, int C, int F) {
     int grid = f.P.ntiles < want ? f.P.ntiles : want;
     if (grid < 8) grid = 8;
     f.grid = (grid + 7) / 8 * 8;
-    const int want3 = device_cus() * 3;
+    const int want3 = device_cus() * (f.ct == 1 ? GATMI_FWDGF_OCC : 3);
     grid = f.P.ntiles < want3 ? f.P.ntiles : want3;
     if (grid < 8) grid = 8;
     f.grid_fwd = (grid + 7) / 8 * 8;
