@@ -511,7 +511,9 @@ constexpr size_t kSplitImgElems = (size_t)3 * kSplitMaxCols * kSplitMaxCols;
 bool split3_covers(const gatmi_shape &s) {
     if (s.heads < 1 || s.channels < 1 || s.in_features < 1 || s.num_nodes < 4096) return false;
     const SplitGeo g = split_geo(s);
-    return s.in_features % 8 == 0 && g.DpP <= kSplitMaxCols && g.Fp32 <= kSplitMaxCols;
+    // Dp is the K of the d_x product: whole 8-element fragments there too (a narrow last layer --
+    // conv3 into 2 classes: Dp = 4 -- stays on the tiled f32 kernels)
+    return s.in_features % 8 == 0 && g.Dp % 8 == 0 && g.DpP <= kSplitMaxCols && g.Fp32 <= kSplitMaxCols;
 }
 
 size_t split3_workspace_bytes(const gatmi_shape &s) {
@@ -542,7 +544,11 @@ static int launch_split3_gemm(int tiles_n, const float *A, int lda, const uint16
     long long blocks = (tiles + tpb - 1) / tpb;
     blocks = (blocks + 7) / 8 * 8;                             // the XCD-contiguous order
     const int dev = device_index();
-    const unsigned head_magic = 65536u / (unsigned)(HEAD4 ? Cp / 4 : Cp / 8) + 1u;
+    // only the FIX kernels use it (and the check above gives them Cp % 8 == 0 or HEAD4); a narrow last
+    // layer without FIX (conv3 of /root/reference/gat/model.py:30 into 2 classes: Cp = 4) has no
+    // fragment-sized head -- the division by Cp / 8 = 0 here ended the process with SIGFPE from 4096 rows on
+    const unsigned hdiv = (unsigned)(HEAD4 ? Cp / 4 : Cp / 8);
+    const unsigned head_magic = hdiv ? 65536u / hdiv + 1u : 0u;
 #define GATMI_SPLIT3_GEMM(NTV)                                                                       \
     case NTV: {                                                                                      \
         auto kern = split3_gemm_kernel<NTV, FIX, ADST, HEAD4>;                                       \

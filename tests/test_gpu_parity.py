@@ -451,6 +451,25 @@ def test_input_aggregation_row_per_lane_group(cuda, n, f, h, c, p, graph):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("n,f,h,c", [(4100, 240, 1, 2), (4500, 240, 1, 5), (4099, 256, 1, 47), (5000, 240, 2, 3),
+                                     (4200, 64, 1, 1)])
+def test_narrow_last_layer_beyond_4096_rows(cuda, n, f, h, c):
+    """conv3 of /root/reference/gat/model.py:30 (8 * hidden -> num_classes, one head) on more than
+    4096 nodes, where the projection takes the split GEMMs: a head narrower than one 8-column
+    fragment (Cp = 4, 8, 48).  Round 3: the forward divided by Cp / 8 = 0 on the host there (SIGFPE
+    in gatmi_project_fwd) -- every test of the model ran on fewer rows."""
+    from gat_amd import synth
+    ei = synth.out_degree_k_graph(n, 5, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 11)
+    x, w, a_s, a_d, b, go = inputs
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
+    out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs)
+    close(out, ref_out, "out")
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    for k in ref_g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+
+
 FUSED_SHAPES = [  # n, f, h, c, p
     (3001, 25, 8, 30, 0.0), (3001, 25, 8, 30, 0.425), (9, 25, 8, 30, 0.0), (31, 25, 8, 24, 0.3),
     (32, 25, 8, 32, 0.0), (33, 25, 8, 28, 0.2), (1000, 17, 6, 9, 0.3), (1777, 32, 5, 16, 0.0),
