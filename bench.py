@@ -149,7 +149,7 @@ def main():
     achieved = kb[dom] / (avg[dom] * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic(args.workload, dom)
     s8d = survey_8d_bytes(n, ep, h, c)
-    path = "input-side aggregation" if "inagg_fwd" in avg else "projected rows"
+    path = "input-side aggregation" if ("inagg_fwd" in avg or "inagg_fwd_fused" in avg) else "projected rows"
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,

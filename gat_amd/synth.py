@@ -84,4 +84,9 @@ def kernel_bytes(n, e, h, d, f, feat_bytes=4):
         # row-local reads and Z, q stay f32
         "inagg_fwd": e * (rowb + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h),
         "inagg_bwd_edge": e * (rowb + 4) + n * (4 + 4 * fs + 8 * h * fp + 8 * h),
+        # the fused tiles of the row-per-group layout (run.py's conv1): the forward also
+        # writes the out row (4 D) -- the separate out = Z W^T product and its re-read of Z are gone --;
+        # the backward reads the grad_out row (4 D) and Z once, q never exists in HBM
+        "inagg_fwd_fused": e * (rowb + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h + 4 * d),
+        "inagg_bwd_fused": e * (rowb + 4) + n * (4 + 4 * fs + 4 * d + 4 * h * fp + 8 * h),
     }
