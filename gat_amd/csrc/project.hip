@@ -1288,6 +1288,294 @@ static int fwd_splits(int N, int Dp, int F, size_t slab_floats) {
     return want < 2 ? 1 : (int)want;
 }
 
+// ---------------------------------------------------------------------------------
+// Narrow last layer: conv3 of /root/reference/gat/model.py:30 projects 8 * hidden features onto
+// num_classes channels of one head (2 classes: Dp = 4).  The MFMA tiles ran these products at 2.2 TB/s
+// (a 128 x 64 tile for 4 columns); they are streams of x: a row per group of lanes (a float4 of the row
+// each), Dp dot products per row reduced by Dp-to-1 trading stages and a butterfly, and in the
+// backward ONE pass over x that writes d_x = d_h W and accumulates d_W = d_h^T x in registers
+// (reads x once, writes d_x once: the two GEMMs read x and d_h twice and wrote a slab per split).
+// Dp = 4 or 8, F % 4 == 0, at least Dp lanes per row, Dp * (float4 per lane) <= 8.
+// ---------------------------------------------------------------------------------
+#ifndef GATMI_NARROW_UN
+#define GATMI_NARROW_UN 2
+#endif
+// d_weight[(h*C + c), f] = sum_z slab[z][(h*Cp + c), f] for the hundreds of slabs of the streaming
+// kernel: 16 outputs x 16 groups of slabs per block, four loads in flight per thread (one thread per
+// output walking 1024 slabs took 0.16 ms for conv3's 480 outputs)
+__global__ __launch_bounds__(256) void reduce_dweight_wide_kernel(const float *slab, int nsplit, int H, int C, int Cp,
+                                                                  int F, float *dw) {
+    __shared__ float red[256];
+    const long long tot = (long long)H * C * F;
+    const size_t slab_elems = (size_t)H * Cp * F;
+    const long long i = blockIdx.x * 16ll + (threadIdx.x & 15);
+    const int rg = threadIdx.x >> 4;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < tot) {
+        const int f = (int)(i % F), r = (int)(i / F), h = r / C, c = r % C;
+        const float *src = slab + ((size_t)h * Cp + c) * F + f;
+        int z = rg;
+        for (; z + 48 < nsplit; z += 64) {
+            s0 += src[(size_t)z * slab_elems];
+            s1 += src[(size_t)(z + 16) * slab_elems];
+            s2 += src[(size_t)(z + 32) * slab_elems];
+            s3 += src[(size_t)(z + 48) * slab_elems];
+        }
+        for (; z < nsplit; z += 16) s0 += src[(size_t)z * slab_elems];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && i < tot) {
+        float t = 0.f;
+        for (int q = 0; q < 16; ++q) t += red[threadIdx.x + q * 16];
+        dw[i] = t;
+    }
+}
+
+template <int S> __device__ __forceinline__ float narrow_xor(float v) {
+    if constexpr (S == 1) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    else if constexpr (S == 2) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    else return __shfl_xor(v, S, 64);
+}
+// v[d] = this lane's part of dot d; returns the whole dot of index bitrev(lane mod DP) over the gl lanes of the row
+template <int DP> __device__ __forceinline__ float narrow_reduce(float (&v)[DP], int lane, int gl) {
+    {
+        constexpr int n = DP / 2;
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const float keep = up ? v[n + i] : v[i], send = up ? v[i] : v[n + i];
+            v[i] = keep + narrow_xor<1>(send);
+        }
+    }
+    {
+        constexpr int n = DP / 4;
+        const bool up = (lane >> 1) & 1;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const float keep = up ? v[n + i] : v[i], send = up ? v[i] : v[n + i];
+            v[i] = keep + narrow_xor<2>(send);
+        }
+    }
+    if constexpr (DP == 8) {
+        const bool up = (lane >> 2) & 1;
+        const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + narrow_xor<4>(send);
+    }
+    float c = v[0];
+    for (int o = DP; o < gl; o <<= 1) c += __shfl_xor(c, o, 64);
+    return c;
+}
+template <int DP> __device__ __forceinline__ int narrow_owner(int lane) {   // the dot index lane owns after narrow_reduce
+    constexpr int L = DP == 4 ? 2 : 3;
+    int d = 0;
+#pragma unroll
+    for (int b = 0; b < L; ++b) d |= ((lane >> b) & 1) << (L - 1 - b);
+    return d;
+}
+
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
+// hp[n, d] = <x[n, :], wp[d, :]> (d < DP = H Cp, wp zero in the padded channels), a_dst[n, h] = <hp[n, h, :], att_p[h, :]>
+template <int DP, int KS>
+__global__ __launch_bounds__(256) void proj_narrow_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wp,
+                                                              const float *__restrict__ att_p, long long n, int F,
+                                                              int glog, int H, int Cp, float *__restrict__ hp,
+                                                              float *__restrict__ a_dst) {
+    constexpr int UN = KS == 1 ? 4 : 2;                           // rows in flight per lane group
+    const int lane = threadIdx.x & 63, gl = 1 << glog, sl = lane & (gl - 1), rsub = lane >> glog;
+    const int rpw = 64 >> glog, lph = F >> 2;
+    nf4 w[DP][KS];
+#pragma unroll
+    for (int d = 0; d < DP; ++d)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int sub = sl + k * gl;
+            w[d][k] = sub < lph ? *reinterpret_cast<const nf4 *>(wp + (size_t)d * F + sub * 4) : nf4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int dl = narrow_owner<DP>(lane);
+    const float attv = att_p ? att_p[dl] : 0.f;
+    const long long wave = blockIdx.x * 4ll + (threadIdx.x >> 6), nwaves = gridDim.x * 4ll;
+    for (long long row0 = wave * rpw * UN; row0 < n; row0 += nwaves * rpw * UN) {
+        nf4 xv[UN][KS];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long row = row0 + u * rpw + rsub;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int sub = sl + k * gl;
+                xv[u][k] = (row < n && sub < lph) ? *reinterpret_cast<const nf4 *>(x + row * F + sub * 4)
+                                                   : nf4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long row = row0 + u * rpw + rsub;
+            float v[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+                    acc += (xv[u][k][0] * w[d][k][0] + xv[u][k][1] * w[d][k][1]) +
+                           (xv[u][k][2] * w[d][k][2] + xv[u][k][3] * w[d][k][3]);
+                v[d] = acc;
+            }
+            const float dot = narrow_reduce<DP>(v, lane, gl);     // of channel dl, in every lane of the row
+            if (row < n && sl < DP) hp[row * DP + dl] = dot;
+            if (a_dst) {
+                // <hp[n, h, :], att_p[h, :]>: the Cp (4 or 8) owners of a head are neighbouring lanes
+                // the owners' channel indices are bit-reversed lane indices: with one head all DP
+                // owners add up; with two heads of 4 channels (DP 8) the head is lane bit 0
+                float t = dot * attv;
+                if (H == 1) {
+                    t += narrow_xor<1>(t);
+                    t += narrow_xor<2>(t);
+                    if (DP == 8) t += narrow_xor<4>(t);
+                } else {
+                    t += narrow_xor<2>(t);
+                    t += narrow_xor<4>(t);
+                }
+                if (row < n && sl < H) a_dst[row * H + dl / Cp] = t;
+            }
+        }
+    }
+}
+
+// d_x[n, :] = sum_d dh[n, d] wp[d, :],  slab[block][d, :] = sum over the block's rows of dh[n, d] x[n, :],
+// dh[n, d] = d_hp[n, d] + d_a_dst[n, head(d)] att_p[d]
+template <int DP, int KS>
+__global__ __launch_bounds__(256) void proj_narrow_bwd_kernel(const float *__restrict__ x, const float *__restrict__ wp,
+                                                              const float *__restrict__ d_hp,
+                                                              const float *__restrict__ d_a_dst,
+                                                              const float *__restrict__ att_p, long long n, int F,
+                                                              int glog, int H, int Cp, float *__restrict__ d_x,
+                                                              float *__restrict__ slab) {
+    constexpr int UN = GATMI_NARROW_UN;                           // rows in flight per lane group
+    __shared__ nf4 red[4][DP][64];
+    const int lane = threadIdx.x & 63, gl = 1 << glog, sl = lane & (gl - 1), rsub = lane >> glog;
+    const int rpw = 64 >> glog, lph = F >> 2, wv = threadIdx.x >> 6;
+    nf4 w[DP][KS], acc[DP][KS];
+    float att[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+        att[d] = d_a_dst ? att_p[d] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int sub = sl + k * gl;
+            w[d][k] = (d_x && sub < lph) ? *reinterpret_cast<const nf4 *>(wp + (size_t)d * F + sub * 4) : nf4{0.f, 0.f, 0.f, 0.f};
+            acc[d][k] = nf4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const long long wave = blockIdx.x * 4ll + wv, nwaves = gridDim.x * 4ll;
+    for (long long row0 = wave * rpw * UN; row0 < n; row0 += nwaves * rpw * UN) {
+        nf4 xv[UN][KS];
+        float dh[UN][DP];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long row = row0 + u * rpw + rsub;
+            const bool on = row < n;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int sub = sl + k * gl;
+                xv[u][k] = (on && sub < lph) ? *reinterpret_cast<const nf4 *>(x + row * F + sub * 4) : nf4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < DP / 4; ++q) {
+                const nf4 t = on ? *reinterpret_cast<const nf4 *>(d_hp + row * DP + 4 * q) : nf4{0.f, 0.f, 0.f, 0.f};
+                dh[u][4 * q] = t[0]; dh[u][4 * q + 1] = t[1]; dh[u][4 * q + 2] = t[2]; dh[u][4 * q + 3] = t[3];
+            }
+            if (d_a_dst) {
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    const float da = on ? d_a_dst[row * H + d / Cp] : 0.f;
+                    dh[u][d] = fmaf(da, att[d], dh[u][d]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long row = row0 + u * rpw + rsub;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                nf4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < DP; ++d) {
+                    o += w[d][k] * dh[u][d];
+                    acc[d][k] += xv[u][k] * dh[u][d];
+                }
+                const int sub = sl + k * gl;
+                if (d_x && row < n && sub < lph) *reinterpret_cast<nf4 *>(d_x + row * F + sub * 4) = o;
+            }
+        }
+    }
+    if (!slab) return;
+    // the row groups of a wave, then the block's four waves: one slab per block
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                for (int o = gl; o < 64; o <<= 1) acc[d][k][c] += __shfl_xor(acc[d][k][c], o, 64);
+            red[wv][d][lane] = acc[d][k];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < DP * gl; i += 256) {
+            const int d = i / gl, l = i - d * gl, sub = l + k * gl;
+            if (sub < lph) {
+                const nf4 t = (red[0][d][l] + red[1][d][l]) + (red[2][d][l] + red[3][d][l]);
+                *reinterpret_cast<nf4 *>(slab + ((size_t)blockIdx.x * DP + d) * F + sub * 4) = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct NarrowPlan {
+    bool ok;
+    int dp, ks, glog, blocks;
+};
+static NarrowPlan narrow_plan(const gatmi_shape &s) {
+    NarrowPlan p{false, 0, 0, 0, 0};
+    if (option("GATMI_NARROW", 1) == 0 || s.num_nodes < 4096) return p;
+    const int Cp = round_up4(s.channels), Dp = Cp * s.heads, F = s.in_features;
+    if ((Dp != 4 && Dp != 8) || (Cp != 4 && Cp != 8) || F % 4 != 0 || F < 4 * Dp) return p;
+    const int lph = F / 4;
+    int gl = next_pow2(lph);
+    if (gl > 64) gl = 64;
+    const int ks = (lph + gl - 1) / gl;
+    if (gl < Dp || (ks != 1 && ks != 2) || Dp * ks > 8) return p;
+    p.ok = true;
+    p.dp = Dp;
+    p.ks = ks;
+    p.glog = ilog2(gl);
+    const long long rows_per_block = 4ll * (64 / gl) * 8;         // eight trips of a block at least
+    long long b = (s.num_nodes + rows_per_block - 1) / rows_per_block;
+    const long long cap = option("GATMI_NARROW_BLOCKS", 1024);
+    p.blocks = (int)(b > cap ? cap : (b < 1 ? 1 : b));
+    return p;
+}
+
+template <int DP, int KS>
+static void narrow_launch(bool fwd, const NarrowPlan &p, const float *x, const float *wp, const float *d_hp,
+                          const float *d_a_dst, const float *att_p, long long n, int F, int H, int Cp, float *out,
+                          float *a_dst_or_slab, hipStream_t st) {
+    if (fwd)
+        hipLaunchKernelGGL((proj_narrow_fwd_kernel<DP, KS>), dim3(p.blocks), dim3(256), 0, st, x, wp, att_p, n, F,
+                           p.glog, H, Cp, out, a_dst_or_slab);
+    else
+        hipLaunchKernelGGL((proj_narrow_bwd_kernel<DP, KS>), dim3(p.blocks), dim3(256), 0, st, x, wp, d_hp, d_a_dst,
+                           att_p, n, F, p.glog, H, Cp, out, a_dst_or_slab);
+}
+static void narrow_dispatch(bool fwd, const NarrowPlan &p, const float *x, const float *wp, const float *d_hp,
+                            const float *d_a_dst, const float *att_p, long long n, int F, int H, int Cp, float *out,
+                            float *a_dst_or_slab, hipStream_t st) {
+    if (p.dp == 4 && p.ks == 1) narrow_launch<4, 1>(fwd, p, x, wp, d_hp, d_a_dst, att_p, n, F, H, Cp, out, a_dst_or_slab, st);
+    else if (p.dp == 4) narrow_launch<4, 2>(fwd, p, x, wp, d_hp, d_a_dst, att_p, n, F, H, Cp, out, a_dst_or_slab, st);
+    else narrow_launch<8, 1>(fwd, p, x, wp, d_hp, d_a_dst, att_p, n, F, H, Cp, out, a_dst_or_slab, st);
+}
+
 static int dweight_splits(int N, int Dp, int F) {
     const int tiles = ((Dp + 127) / 128) * ((F + 127) / 128);
     int want = 512 / tiles;   // ~512 blocks: enough to fill 256 CUs, half the slab traffic of 1024
@@ -1304,7 +1592,9 @@ extern "C" size_t gatmi_project_workspace_bytes(const gatmi_shape *s) {
     if (!s) return 0;
     const size_t Cp = round_up4(s->channels), Dp = Cp * s->heads, F = s->in_features;
     const size_t wp = align_up(Dp * F * 4);
-    const size_t slab = align_up((size_t)dweight_splits(s->num_nodes, (int)Dp, (int)F) * Dp * F * 4);
+    size_t nslab = (size_t)dweight_splits(s->num_nodes, (int)Dp, (int)F);
+    if (const NarrowPlan np = narrow_plan(*s); np.ok && (size_t)np.blocks > nslab) nslab = (size_t)np.blocks;
+    const size_t slab = align_up(nslab * Dp * F * 4);
     return wp + slab + align_up(Dp * 4) + 256 + split3_workspace_bytes(*s);
 }
 
@@ -1347,6 +1637,22 @@ extern "C" int gatmi_project_fwd(const gatmi_shape *s, const float *x, const flo
     const int Cp = round_up4(C), Dp = H * Cp;
     GATMI_REQUIRE(Cp <= 1024, "channels %d too wide", C);
     if (N == 0) return GATMI_OK;
+    if (const NarrowPlan np = narrow_plan(*s); np.ok) {
+        // a narrow last layer: one streaming pass over x, a_dst from the same kernel
+        const float *wp = padded_weight(s, weight, static_cast<float *>(ws), st);
+        GATMI_HIP(hipGetLastError());
+        float *att_p = nullptr;
+        if (a_dst) {
+            GATMI_REQUIRE(att_dst, "a_dst requested without att_dst");
+            att_p = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)Dp * F * 4));
+            hipLaunchKernelGGL(pad_weight_kernel, dim3(1), dim3(256), 0, st, att_dst, att_p, H, C, Cp, 1);
+            GATMI_HIP(hipGetLastError());
+        }
+        ProfScope ps("proj_fwd_gemm", st);
+        narrow_dispatch(true, np, x, wp, nullptr, nullptr, att_p, N, F, H, Cp, hp, a_dst, st);
+        GATMI_HIP(hipGetLastError());
+        return GATMI_OK;
+    }
     if (split3_mask(s) & 1) {
         // f32-accurate product from three bf16 pieces per operand on the bf16 matrix cores
         ProfScope ps("proj_fwd_gemm", st);
@@ -1416,6 +1722,34 @@ extern "C" int gatmi_project_bwd(const gatmi_shape *s, const float *x, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int N = s->num_nodes, F = s->in_features, H = s->heads, C = s->channels;
     const int Cp = round_up4(C), Dp = H * Cp;
+    if (const NarrowPlan np = narrow_plan(*s); np.ok && N > 0) {
+        // a narrow last layer: d_x and d_weight from ONE pass over x (a slab of d_weight per block)
+        GATMI_REQUIRE(!d_a_dst || att_dst, "d_a_dst given without att_dst");
+        if (!d_weight && !d_x) return GATMI_OK;
+        const float *wp = d_x ? padded_weight(s, weight, static_cast<float *>(ws), st) : nullptr;
+        GATMI_HIP(hipGetLastError());
+        float *slab = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)Dp * F * 4));
+        size_t nslab = (size_t)dweight_splits(N, Dp, F);
+        if ((size_t)np.blocks > nslab) nslab = (size_t)np.blocks;
+        float *att_p = reinterpret_cast<float *>(reinterpret_cast<char *>(slab) + align_up(nslab * Dp * F * 4));
+        if (d_a_dst) {
+            hipLaunchKernelGGL(pad_weight_kernel, dim3(1), dim3(256), 0, st, att_dst, att_p, H, C, Cp, 1);
+            GATMI_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps("proj_bwd_x_gemm", st);
+            narrow_dispatch(false, np, x, wp, d_hp, d_a_dst, att_p, N, F, H, Cp, d_x, d_weight ? slab : nullptr, st);
+            GATMI_HIP(hipGetLastError());
+        }
+        if (d_weight) {
+            ProfScope ps("proj_bwd_w_gemm", st);
+            const long long tot = (long long)H * C * F;
+            hipLaunchKernelGGL(reduce_dweight_wide_kernel, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, st, slab,
+                               np.blocks, H, C, Cp, F, d_weight);
+            GATMI_HIP(hipGetLastError());
+        }
+        return GATMI_OK;
+    }
     if (const int sp = N > 0 ? split3_mask(s) : 0; sp & 6) {
         GATMI_REQUIRE(!d_a_dst || att_dst, "d_a_dst given without att_dst");
         if (int e = split3_project_bwd(s, x, weight, d_hp, d_a_dst, att_dst,

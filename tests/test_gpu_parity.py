@@ -451,19 +451,28 @@ def test_input_aggregation_row_per_lane_group(cuda, n, f, h, c, p, graph):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("narrow", [1, 0], ids=["streaming", "tiles"])
 @pytest.mark.parametrize("n,f,h,c", [(4100, 240, 1, 2), (4500, 240, 1, 5), (4099, 256, 1, 47), (5000, 240, 2, 3),
-                                     (4200, 64, 1, 1)])
-def test_narrow_last_layer_beyond_4096_rows(cuda, n, f, h, c):
+                                     (4200, 64, 1, 1), (4300, 512, 1, 4), (4100, 300, 1, 2), (4127, 16, 1, 3),
+                                     (4100, 264, 1, 8), (4097, 320, 2, 4)])
+def test_narrow_last_layer_beyond_4096_rows(cuda, n, f, h, c, narrow):
     """conv3 of /root/reference/gat/model.py:30 (8 * hidden -> num_classes, one head) on more than
     4096 nodes, where the projection takes the split GEMMs: a head narrower than one 8-column
     fragment (Cp = 4, 8, 48).  Round 3: the forward divided by Cp / 8 = 0 on the host there (SIGFPE
-    in gatmi_project_fwd) -- every test of the model ran on fewer rows."""
-    from gat_amd import synth
+    in gatmi_project_fwd) -- every test of the model ran on fewer rows.
+    H * Cp = 4 or 8 runs on the streaming kernels of project.hip (proj_narrow_*: a row per group of
+    lanes, d_x and d_W from one pass over x; one or two float4 of a row per lane, one or two heads);
+    GATMI_NARROW=0 keeps the MFMA tiles; (47 classes, F = 512 with 8 columns: tiles either way)."""
+    from gat_amd import _lib, synth
     ei = synth.out_degree_k_graph(n, 5, seed=n)
     inputs = cases.layer_inputs(n, f, h, c, seed=n + 11)
     x, w, a_s, a_d, b, go = inputs
     ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go)
-    out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs)
+    _lib.set_option("GATMI_NARROW", narrow)
+    try:
+        out, g = run_layer(cuda, ei, n, f, h, c, 0.0, None, 512, inputs)
+    finally:
+        _lib.set_option("GATMI_NARROW", -1)
     close(out, ref_out, "out")
     summand = float(go.abs().max() * (x @ w.t()).abs().max())
     for k in ref_g:
