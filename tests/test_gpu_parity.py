@@ -1048,6 +1048,21 @@ def test_partition_input_aggregation_on_bf16_rows(cuda, gname, sname, world):
     _partition_input_aggregation(cuda, gname, sname, world, "edges", rows16=True)
 
 
+@pytest.mark.parametrize("fused", [7, 0], ids=["fused", "separate"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_partition_input_aggregation_on_fused_tiles(cuda, world, fused):
+    """Rectangular mode on the fused tiles (run.py's conv1 on its 5-neighbour graph, cut into 2 / 3
+    destination ranges: the ranks' tiles start at a destination offset, the last tile of a range is
+    ragged, x_i of the d_wd step comes from the offset row of the gathered table)."""
+    from gat_amd import _lib
+    _lib.set_option("GATMI_FUSED", fused)
+    try:
+        _partition_input_aggregation(cuda, "knn", "conv1_h30", world, "edges", rows16=False)
+        _partition_input_aggregation(cuda, "knn", "conv1_h30", world, "nodes", rows16=False)
+    finally:
+        _lib.set_option("GATMI_FUSED", -1)
+
+
 def _partition_input_aggregation(cuda, gname, sname, world, balance, rows16):
     """Input-side aggregation in rectangular mode (what a rank of the multi-GPU layer runs):
     every rank packs its own rows, the packed table is their concatenation (the all-gather),
