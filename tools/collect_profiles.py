@@ -73,6 +73,20 @@ def main():
                 out["kernels"][tag_] = traffic[n]
                 break
     json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    # the run.py-shaped layer at 10^6 nodes (fused tiles): kernel table + the two counter passes
+    rstats = glob.glob(os.path.join(src, "stats_runpy", "**", "*kernel_stats.csv"), recursive=True)
+    if rstats:
+        shutil.copy(rstats[0], os.path.join(dst, f"{prefix}_runpy1m_kernel_stats.csv"))
+        rf, rw = pmc(os.path.join(src, "pmc_fetch_runpy")), pmc(os.path.join(src, "pmc_write_runpy"))
+        rl = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload runpy1m --steps 2 "
+              "--warmup 1; KiB per dispatch; HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024"]
+        for k in sorted(set(rf) | set(rw)):
+            f, nf = rf.get(k, (0.0, 0))
+            w, nw = rw.get(k, (0.0, 0))
+            rl.append(f"{k:28s} FETCH_SIZE: avg {f:.1f} (n={nf})  WRITE_SIZE: avg {w:.1f} (n={nw})  "
+                      f"HBM bytes {int((2 * f + w) * 1024)}")
+        open(os.path.join(dst, f"pmc_{prefix}_runpy1m.txt"), "w").write("\n".join(rl) + "\n")
+        print("\n".join(rl))
     print(open(os.path.join(dst, f"pmc_{prefix}.txt")).read())
     print(json.dumps(out["kernels"]))
 
