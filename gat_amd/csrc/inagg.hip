@@ -2441,7 +2441,8 @@ __global__ __launch_bounds__(256) void inagg_finalize_kernel(
 // used as two MFMA steps (the K order of a product is free as long as A and B agree) -- with a
 // row stride of 2 mod 4 floats: 32 rows x 2 banks cover the 64 banks once.
 // ---------------------------------------------------------------------------------
-#ifndef GATMI_BWDGF_E   // gathered rows in flight per lane group of the fused backward: 4 / 8 spill (1.95 / 2.11 against 1.64 ms at 10^6 rows)
+#ifndef GATMI_BWDGF_E   // gathered rows in flight per lane group of the fused backward: 3 / 4 / 8 run 1.75 / 1.95 / 2.11 against 1.64 ms
+                        // at 10^6 rows (spills), and no better with q of the row read from LDS per use instead of held (1.74 / 2.08 / 2.41)
 #define GATMI_BWDGF_E 2
 #endif
 #ifndef GATMI_FWDGF_OCC  // blocks per CU the fused forward (C <= 32) is compiled for: 4 (128 registers) 0.89 ms at 10^6 rows, 3: 0.97
@@ -2968,7 +2969,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                 cj = n > 0 ? A.col[el] : 0;
                 kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
             }
-            for (int e0 = 0; e0 < nw; e0 += kE) {             // a whole chunk of rows in flight: one latency per chunk
+            for (int e0 = 0; e0 < nw; e0 += kE) {             // kE rows in flight
                 f4 v[kE];
                 float as[kE];
                 unsigned sb[kE];
