@@ -2456,6 +2456,7 @@ struct FuseArgs {
     float *out;          // [N, H*C] (forward)
     float *slab;         // [blocks][H][C][F] (backward)
     float *gsum;         // [blocks][H*C] or null (backward)
+    float *qout;         // backward without the edge pass: q [N, H*Fp]
     int C, F, N, ntiles;
     int dbg;             // GATMI_FUSE_DBG: ablation bits (wrong results; timing only)
     int zs;              // forward: row stride of the Z tile; backward: of the q tile (floats)
@@ -2704,7 +2705,10 @@ __global__ __launch_bounds__(256, CT == 1 ? GATMI_FWDGF_OCC : 3) void inagg_fwdg
     }
 }
 
-template <int CT, int VW>
+// EDGE == false: the products only -- q = g W written to HBM (P.qout, whole lines through the LDS tile),
+// d_W slabs and g sums as above; the edge pass then runs as inagg_bwdg_kernel.  For graphs beyond
+// kFuseBwdMaxRows: one pass over grad_out instead of the two of the separate q and d_W products.
+template <int CT, int VW, bool EDGE>
 __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, const FuseArgs P) {
     extern __shared__ __attribute__((aligned(16))) float fuse_lds[];
     // LDS: q of the tile [32 rows][zs] | per wave: g, its two heads [32 rows][gs] | per wave: [8][8]
@@ -2842,9 +2846,11 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
     for (int h = 0; h < 8; ++h) ys[h] = zero4();
     f32x4t ydm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // d_wd [head][f] by 16x16x4 MFMAs, f < 16 | f >= 16
     int tile = xcd_contiguous_block();
-    TileMeta N1;
-    meta_row(tile, N1);
-    meta_cols(N1);
+    TileMeta N1{};
+    if constexpr (EDGE) {
+        meta_row(tile, N1);
+        meta_cols(N1);
+    }
     float vg[2][NI][VW], zb[16];
     request_g(tile, P.C, vg);
     {
@@ -2876,7 +2882,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         // the loads the products and the edge pass wait for later, issued once the staging registers
         // of grad_out are free: weight fragments, the second head's Z tile, the wave's own Z rows
         f4 z4[8];
-        {
+        if constexpr (EDGE) {
             const int vo = pok ? ((wv * 8 + g) * HF + p * 4) * 4 : kOob;
 #pragma unroll
             for (int h = 0; h < 8; ++h)
@@ -2928,6 +2934,22 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         lds_barrier();                                            // the q tile is whole
+        if constexpr (!EDGE) {
+            // q rows of the tile are one contiguous block of HBM: whole lines from the LDS tile
+            float *qg = P.qout + (size_t)row0 * HF;
+            for (int r = wv; r < trows; r += 4)
+                for (int c4 = lane; c4 < (HF >> 2); c4 += 64)
+                    stv4(qg + r * HF + 4 * c4, ldv4(qt + r * zs + 4 * c4));
+            {   // the next tile's grad_out columns and first Z tile
+                const int tn = tile + gridDim.x;
+                request_g(tn, C, vg);
+                const int rows = tn < P.ntiles ? min(32, P.N - tn * 32) : 0;
+                load_zb(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.zin) + (size_t)(rows > 0 ? tn * 32 : 0) * HF,
+                                                          0, rows * HF * 4, 0x00020000), 0, zb);
+            }
+            lds_barrier();                                        // before the next tile's q stores
+            continue;
+        }
         // 4. the edge pass of the wave's 8 rows (inagg_bwdg_kernel's, q from LDS)
         const TileMeta M = N1;
         meta_row(tile + gridDim.x, N1);                           // in flight across the edge pass
@@ -3033,6 +3055,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
     const int C = P.C;
     // the block's partial sums: d_ws | d_wd rows (8 groups, then 4 waves through LDS), its d_W slab, g sums
     float *red = fuse_lds;                                        // [2][4][256], over the q tile
+    if constexpr (EDGE) {
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
 #pragma unroll
@@ -3054,6 +3077,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
             const float *src = red + which * 4 * 256 + r;
             dst[which * HF + hh * A.Fp + ff] = (src[0] + src[256]) + (src[512] + src[768]);
         }
+    }
     }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
@@ -3178,7 +3202,7 @@ static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr,
     // the backward whatever the size.  By default the backward is fused up to kFuseBwdMaxRows rows:
     // beyond, with every CU busy for long, the separate kernels' higher occupancy wins (runpy1m: 1.64
     // against 1.52 ms; runpy100k: 0.19 against 0.24)
-    const int mode = option("GATMI_FUSED", 3);
+    const int mode = option("GATMI_FUSED", 11);
     if ((mode & pass) == 0 || bf16_rows || C > kFuseMaxC) return false;
     if (pass == 2 && !(mode & 4) && gr->num_dst > kFuseBwdMaxRows) return false;
     // the backward holds a head pair's d_W in registers beside the edge pass: one 32-channel tile
@@ -3187,6 +3211,13 @@ static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr,
     if (pass == 2 && (C > 32 || C % 2 != 0)) return false;
     if (gr->plan.n_split_rows != 0 || gr->plan.n_items != gr->num_dst) return false;
     return group_rows(g, A);
+}
+// q = g W and d_W = g^T Z (+ column sums of g) from one pass over grad_out (inagg_bwdgf_kernel<.., false>):
+// any graph -- the kernel never looks at it --, up to 8 heads, rows of at most 8 float4, even C <= 32.
+// GATMI_FUSED bit 3.
+static bool fused_products_cover(const InGeo &g, int H, int C) {
+    if ((option("GATMI_FUSED", 11) & 8) == 0) return false;
+    return g.G == 64 && H <= 8 && g.lph <= 8 && C <= 32 && C % 2 == 0;
 }
 struct FusePlan {
     int grid, grid_fwd, ct, vw;
@@ -3249,11 +3280,11 @@ static int fused_fwd_launch(const FusePlan &f, const InArgs &A, float *wimg, hip
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
-template <int CT, int VW>
+template <int CT, int VW, bool EDGE>
 static int fused_bwd_launch_t(const FusePlan &f, const InArgs &A, const FuseArgs &P, hipStream_t st) {
     static size_t granted[kMaxDevices] = {};
-    if (int e = grant_lds(inagg_bwdgf_kernel<CT, VW>, f.lds_bwd, &granted[device_index()])) return e;
-    hipLaunchKernelGGL((inagg_bwdgf_kernel<CT, VW>), dim3(f.grid), dim3(256), f.lds_bwd, st, A, P);
+    if (int e = grant_lds(inagg_bwdgf_kernel<CT, VW, EDGE>, f.lds_bwd, &granted[device_index()])) return e;
+    hipLaunchKernelGGL((inagg_bwdgf_kernel<CT, VW, EDGE>), dim3(f.grid), dim3(256), f.lds_bwd, st, A, P);
     GATMI_HIP(hipGetLastError());
     return GATMI_OK;
 }
@@ -3262,8 +3293,8 @@ static int fused_bwd_launch(const FusePlan &f, const InGeo &g, const InArgs &A, 
     P.zs = g.HF + 4;                         // the q tile is read back as float4
     const int lpr = next_pow2(P.C / f.vw);   // lanes per row of one head's columns of grad_out
     P.lpr_log = ilog2(lpr < 2 ? 2 : lpr);
-    if (f.vw == 4) return fused_bwd_launch_t<1, 4>(f, A, P, st);
-    return fused_bwd_launch_t<1, 2>(f, A, P, st);
+    if (P.qout) return f.vw == 4 ? fused_bwd_launch_t<1, 4, false>(f, A, P, st) : fused_bwd_launch_t<1, 2, false>(f, A, P, st);
+    return f.vw == 4 ? fused_bwd_launch_t<1, 4, true>(f, A, P, st) : fused_bwd_launch_t<1, 2, true>(f, A, P, st);
 }
 
 static int in_launch_rows(InKind k, const InGeo &g, const InArgs &A, int grid, hipStream_t st) {
@@ -3816,7 +3847,21 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         GATMI_HIP(hipGetLastError());
         return GATMI_OK;
     }
-    if (N > 0) {
+    const bool k1 = N > 0 && fused_products_cover(geo, H, C);
+    FusePlan fk{};
+    if (k1) {
+        // q = g W and the d_W slabs from one pass over grad_out; the edge pass below reads q from HBM
+        ProfScope ps("inagg_q_dw_fused", st);
+        fk = fuse_plan(geo, N, H, C, F);
+        InArgs Ak = A;
+        Ak.zin = z;
+        fk.P.w = a->weight;
+        fk.P.gout = grad_out;
+        fk.P.slab = w.slab;
+        fk.P.gsum = d_bias ? w.gsum : nullptr;
+        fk.P.qout = w.q;
+        if (int e = fused_bwd_launch(fk, geo, Ak, st)) return e;
+    } else if (N > 0) {
         // q[:, h, :] = g[:, h, :] W_h   (padded columns written as zeros)
         ProfScope ps("inagg_q_gemm", st);
         GemmDesc d{};
@@ -3881,6 +3926,20 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     {
         // slab[split][h] = g[:, h, :]^T Z[:, h, :] over the split's rows
         ProfScope ps("inagg_dw_gemm", st);
+        if (k1) {
+            // the slabs and g sums of the pass above: one row-sum launch, then the closing kernel on single rows
+            const int tot = H * C * F;
+            SumJob j2{w.slab, w.slab_sum, fk.grid, tot, tot};
+            SumJob j3{w.gsum, d_bias ? w.slab_sum + tot : nullptr, fk.grid, H * C, H * C};
+            hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((tot + 15) / 16, 2), dim3(256), 0, st, j2, j3, j3);
+            GATMI_HIP(hipGetLastError());
+            const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
+            hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab_sum, 1, H, C, F, geo.Fp,
+                               a->weight, a->att_src, a->att_dst, w.dwsd, w.slab_sum + tot, d_weight, d_att_src,
+                               d_att_dst, d_bias);
+            GATMI_HIP(hipGetLastError());
+            return GATMI_OK;
+        }
         if (N > 0) {
             GemmDesc d{};
             d.a_kmajor = true; d.b_kmajor = true;

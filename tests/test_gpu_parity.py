@@ -487,14 +487,15 @@ FUSED_SHAPES = [  # n, f, h, c, p
 ]
 
 
-@pytest.mark.parametrize("fused", [7, 1, 0], ids=["fwd_bwd", "fwd", "separate"])
+@pytest.mark.parametrize("fused", [15, 9, 1, 0], ids=["fwd_bwd", "fwd_products", "fwd", "separate"])
 @pytest.mark.parametrize("graph", ["knn5", "self_loops_only", "degree40"])
 @pytest.mark.parametrize("n,f,h,c,p", FUSED_SHAPES)
 def test_input_aggregation_fused_tiles(cuda, n, f, h, c, p, graph, fused):
     """The fused 32-row tiles of the row-per-group layout (inagg_fwdgf / inagg_bwdgf: 5..8 heads, rows
     of at most 8 float4, no row cut into segments; the backward for even C <= 32, the forward up to
-    C = 64) with GATMI_FUSED = 7 (both passes whatever the size), 1 (forward only) and 0 (the separate
-    kernels they replace): node counts around the tile size, channel counts around the 32-wide MFMA
+    C = 64) with GATMI_FUSED = 15 (both passes whatever the size), 9 (forward, and in the backward the
+    products q = g W and d_W = g^T Z from one pass over grad_out ahead of the separate edge kernel),
+    1 (forward only) and 0 (the separate kernels they replace): node counts around the tile size, channel counts around the 32-wide MFMA
     tiles, odd head counts (a wave with one head, a wave with none), with and without dropout, on
     the 5-neighbour graph of /root/reference/gat/converter.py:7-15, on rows that hold their self
     loop only and on rows of 41 edges (six chunks of 8 per row).
@@ -558,6 +559,8 @@ def test_fused_tiles_run_where_they_should(cuda):
     star = torch.stack([torch.arange(n), torch.zeros(n, dtype=torch.long)])     # row 0: 2000 edges, cut
     ts = tags(star, -1)
     assert "inagg_fwd_fused" not in ts and "inagg_bwd_fused" not in ts
+    assert "inagg_q_dw_fused" in ts and "inagg_q_gemm" not in ts                # the products do not look at the graph
+    assert "inagg_q_dw_fused" in tags(knn, 9) and "inagg_q_gemm" in tags(star, 0)
 
 
 @pytest.mark.parametrize("v2", [1, 0], ids=["double_buffered", "tiled"])
@@ -1048,7 +1051,7 @@ def test_partition_input_aggregation_on_bf16_rows(cuda, gname, sname, world):
     _partition_input_aggregation(cuda, gname, sname, world, "edges", rows16=True)
 
 
-@pytest.mark.parametrize("fused", [7, 0], ids=["fused", "separate"])
+@pytest.mark.parametrize("fused", [15, 9, 0], ids=["fused", "fwd_products", "separate"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_partition_input_aggregation_on_fused_tiles(cuda, world, fused):
     """Rectangular mode on the fused tiles (run.py's conv1 on its 5-neighbour graph, cut into 2 / 3
