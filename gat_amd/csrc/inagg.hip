@@ -2865,12 +2865,10 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         // tile loop, held across the edge pass and spilled
         int zs = P.zs, gs = P.gs, cp4 = P.cp4, C = P.C, F = P.F;
         asm volatile("" : "+s"(zs), "+s"(gs), "+s"(cp4), "+s"(C), "+s"(F));
-        const int HC = A.H * C, nk4 = cp4 >> 2;
+        const int nk4 = cp4 >> 2;
         float *qt = fuse_lds;
         float *gtw = fuse_lds + 32 * zs + wv * 32 * gs;
         float *dtw = fuse_lds + 32 * zs + 4 * 32 * gs + wv * 64;
-        const int row = row0 + wv * 8 + g;
-        const bool on = row < P.N;
         // 0. grad_out and the first head's Z tile were requested at the end of the tile before (or
         //    ahead of the loop): grad_out goes to the wave's LDS tile now
         const int trows = min(32, P.N - row0);
