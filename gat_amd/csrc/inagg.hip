@@ -104,6 +104,7 @@ struct InArgs {
     float *z, *lse, *part_m, *part_s, *part_acc;
     // backward
     const float *q, *zin, *lsein;
+    const float *sin;    // [num_dst, H] S = <q, Z> per (row, head) when the products pass made it (inagg_bwdg only), or null
     float *part_y;       // [waves][2][H*Fp]
     // streaming kernels (LDS-DMA ring): chunk queue
     int *queue;
@@ -1943,17 +1944,25 @@ __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const I
             end = min(A.rowptr[row + 1], beg + A.seg_len);
         }
         f4 q4[8];
-        float sv[8];
+        float S;
+        if (A.sin) {                                              // wave-uniform: S came with q from the products pass
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const bool ld = on && pok && h < A.H;
-            q4[h] = ld ? ldv4(A.q + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
-            const f4 z4 = ld ? ldv4(A.zin + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
-            f2 d = {0.f, 0.f};
-            pk_dot4(d, q4[h], z4);
-            sv[h] = d.x + d.y;
+            for (int h = 0; h < 8; ++h)
+                q4[h] = (on && pok && h < A.H) ? ldv4(A.q + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+            S = (on && hlok) ? A.sin[(size_t)row * A.H + hl] : 0.f;
+        } else {
+            float sv[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const bool ld = on && pok && h < A.H;
+                q4[h] = ld ? ldv4(A.q + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+                const f4 z4 = ld ? ldv4(A.zin + (size_t)row * HF + h * A.Fp + p * 4) : zero4();
+                f2 d = {0.f, 0.f};
+                pk_dot4(d, q4[h], z4);
+                sv[h] = d.x + d.y;
+            }
+            S = heads_sum_e<3, 3>(sv, lane);
         }
-        const float S = heads_sum_e<3, 3>(sv, lane);
         const float lse_i = A.lsein[(size_t)row * A.H + hl];
         const float adi = A.a_dst[(size_t)row * A.H + hl];
         float dad = 0.f;
@@ -2457,6 +2466,7 @@ struct FuseArgs {
     float *slab;         // [blocks][H][C][F] (backward)
     float *gsum;         // [blocks][H*C] or null (backward)
     float *qout;         // backward without the edge pass: q [N, H*Fp]
+    float *sout;         //   and S [N, H] = <q, Z> per (row, head), what the edge pass needs of Z
     int C, F, N, ntiles;
     int dbg;             // GATMI_FUSE_DBG: ablation bits (wrong results; timing only)
     int zs;              // forward: row stride of the Z tile; backward: of the q tile (floats)
@@ -2769,13 +2779,17 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         M.cj = n > 0 ? A.col[el] : 0;
         M.kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
     };
-    // B of d_W: Z[row 2 s + half][h Fp + l] of the tile `zrs` spans
-    const int zvo = l < A.Fp ? (half * HF + l) * 4 : kOob;
+    // B of d_W: Z[row][h Fp + l] of the tile `zrs` spans.  Step s of the contraction over the tile's rows
+    // takes row (s & 3) + 8 (s >> 2) + 4 half -- the order in which an MFMA result holds its rows (the K
+    // order of a product is free), so that zb[s] lines up with element s of the q fragment: S = <q, Z> of
+    // a (row, head) is then a reduction of 16 products over the 32 lanes of a half-wave
+    const int zvo = l < A.Fp ? (4 * half * HF + l) * 4 : kOob;
     auto load_zb = [&](const __amdgpu_buffer_rsrc_t zrs, int hh, float (&zb)[16]) {
         const int so = min(h0 + hh, A.H - 1) * A.Fp * 4;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-            zb[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvo, so + 2 * s * HF * 4, 0));
+            zb[s] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvo, so + ((s & 3) + 8 * (s >> 2)) * HF * 4, 0));
     };
     // The wave's columns of the 32 rows of grad_out of a tile: per head, LPR lanes a row (VW floats
     // each), 64 / LPR rows an instruction; buffer loads over the tile's rows (one lane offset, the
@@ -2869,6 +2883,8 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         float *qt = fuse_lds;
         float *gtw = fuse_lds + 32 * zs + wv * 32 * gs;
         float *dtw = fuse_lds + 32 * zs + 4 * 32 * gs + wv * 64;
+        float *stile = fuse_lds + 32 * zs + 4 * 32 * gs + 4 * 64;    // [32 rows][8 heads]: S of the tile
+        (void)stile;
         // 0. grad_out and the first head's Z tile were requested at the end of the tile before (or
         //    ahead of the loop): grad_out goes to the wave's LDS tile now
         const int trows = min(32, P.N - row0);
@@ -2878,15 +2894,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // the loads the products and the edge pass wait for later, issued once the staging registers
-        // of grad_out are free: weight fragments, the second head's Z tile, the wave's own Z rows
-        f4 z4[8];
-        if constexpr (EDGE) {
-            const int vo = pok ? ((wv * 8 + g) * HF + p * 4) * 4 : kOob;
-#pragma unroll
-            for (int h = 0; h < 8; ++h)
-                z4[h] = h < A.H ? __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(zrs, vo, h * A.Fp * 4, 0))
-                                : zero4();
-        }
+        // of grad_out are free: weight fragments, the second head's Z tile
         if (!(P.dbg & 32)) load_wq(P.w, C, F, nk4);
         float zn[16];
         if (nh > 1 && !(P.dbg & 32)) load_zb(zrs, 1, zn);
@@ -2901,10 +2909,10 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                 for (int ct = 0; ct < CT; ++ct) {
                     if (P.dbg & 2) break;
                     const int c = ct * 32 + l;
-                    const float *gp = gtw + half * gs + hh * cp4 + min(c, C - 1);
+                    const float *gp = gtw + 4 * half * gs + hh * cp4 + min(c, C - 1);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
-                        float a = gp[2 * s * gs];
+                        float a = gp[((s & 3) + 8 * (s >> 2)) * gs];
                         a = c < C ? a : 0.f;
                         gsa[hh][ct] += a;
                         dw[hh][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hh == 0 ? zb[s] : zn[s], dw[hh][ct], 0, 0, 0);
@@ -2927,6 +2935,24 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
                     for (int r = 0; r < 16; ++r) {
                         const int rb = (r & 3) + 8 * (r >> 2);
                         (qt + rb * zs)[4 * half * zs + h * A.Fp + l] = d[r];
+                    }
+                }
+                {   // S[row, h] = <q[row, h, :], Z[row, h, :]> = sum_e alpha_e d alpha_e of the row: 16 rows per
+                    // lane, summed over the half-wave's 32 columns by 16-to-1 trading stages and one step
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = d[r] * (hh == 0 ? zb[r] : zn[r]);
+                    trade_stage<0, 16>(t, lane);
+                    trade_stage<1, 16>(t, lane);
+                    trade_stage<2, 16>(t, lane);
+                    trade_stage<3, 16>(t, lane);
+                    const float sv = t[0] + lane_xor<16>(t[0]);
+                    // lane l of a half now holds row index bitrev4(l mod 16) of the fragment order
+                    const int r = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
+                    const int rowt = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (l < 16) {
+                        if constexpr (EDGE) stile[rowt * 8 + h] = sv;
+                        else if (row0 + rowt < P.N) P.sout[(size_t)(row0 + rowt) * A.H + h] = sv;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -2953,16 +2979,10 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
         meta_row(tile + gridDim.x, N1);                           // in flight across the edge pass
         const int beg = M.beg, end = M.end;
         f4 q4[8];
-        float sv[8];
         const float *qr = qt + (wv * 8 + g) * zs + p * 4;
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            q4[h] = (pok && h < A.H) ? ldv4(qr + h * A.Fp) : zero4();
-            f2 d = {0.f, 0.f};
-            pk_dot4(d, q4[h], z4[h]);
-            sv[h] = d.x + d.y;
-        }
-        const float S = heads_sum_e<3, 3>(sv, lane);
+        for (int h = 0; h < 8; ++h) q4[h] = (pok && h < A.H) ? ldv4(qr + h * A.Fp) : zero4();
+        const float S = hlok ? stile[(wv * 8 + g) * 8 + hl] : 0.f;
         // B of the d_wd steps after the edge pass: the wave's own x rows, requested ahead of it
         float xb[2][2];
 #pragma unroll
@@ -3235,7 +3255,7 @@ static FusePlan fuse_plan(const InGeo &g, int N, int H, int C, int F) {
     f.ct = (C + 31) / 32;
     f.vw = C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);
     f.lds_fwd = (size_t)32 * (f.P.zs > H * C ? f.P.zs : H * C) * 4;   // the Z tile, then the out tile over it
-    f.lds_bwd = ((size_t)32 * (g.HF + 4) + (size_t)4 * 32 * f.P.gs + 4 * 64) * 4;   // q tile | g tiles | d_u sums
+    f.lds_bwd = ((size_t)32 * (g.HF + 4) + (size_t)4 * 32 * f.P.gs + 4 * 64 + 32 * 8) * 4;   // q tile | g tiles | d_u sums | S tile
     if (f.lds_bwd < 2 * 4 * 256 * 4) f.lds_bwd = 2 * 4 * 256 * 4;   // the closing sums of the block
     // two blocks per CU are resident in the backward (three in the forward); a block walks its
     // tiles with barriers, so blocks beyond the resident ones only add tails
@@ -3763,7 +3783,7 @@ extern "C" int gatmi_inagg_fwd(const gatmi_graph *g, const gatmi_inagg *a, float
 
 namespace {
 struct InBwdWs {
-    float *q, *part_y, *dwsd, *slab, *gsum, *bdiag, *slab_sum;
+    float *q, *part_y, *dwsd, *slab, *gsum, *bdiag, *slab_sum, *sdot;
     int waves, nsplit;
     size_t bytes;
 };
@@ -3785,6 +3805,7 @@ InBwdWs carve_in_bwd(const gatmi_graph *g, const gatmi_shape *s, const InGeo &ge
     w.gsum = cv.take<float>((size_t)slabs * s->heads * s->channels);
     w.bdiag = cv.take<float>((size_t)s->heads * s->channels * 4 * geo.Fp);   // head groups of <= 4
     w.slab_sum = cv.take<float>((size_t)s->heads * s->channels * (s->in_features + 1));   // fused backward: summed slabs | g sums
+    w.sdot = cv.take<float>(N * s->heads);   // S = <q, Z> per (row, head) from the products pass
     w.bytes = cv.off + 256;
     return w;
 }
@@ -3858,6 +3879,7 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         fk.P.slab = w.slab;
         fk.P.gsum = d_bias ? w.gsum : nullptr;
         fk.P.qout = w.q;
+        fk.P.sout = w.sdot;
         if (int e = fused_bwd_launch(fk, geo, Ak, st)) return e;
     } else if (N > 0) {
         // q[:, h, :] = g[:, h, :] W_h   (padded columns written as zeros)
@@ -3896,6 +3918,7 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
     A.zin = z;
     A.lsein = lse;
     A.part_y = w.part_y;
+    if (k1 && !a->xs16 && group_rows(geo, A)) A.sin = w.sdot;   // inagg_bwdg_kernel then leaves the Z rows alone
     {
         ProfScope ps("inagg_bwd_edge", st);
         // every wave of the grid writes its partial row, also when it had no work item
