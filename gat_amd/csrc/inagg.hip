@@ -2926,6 +2926,7 @@ __global__ __launch_bounds__(256, 2) void inagg_bwdgf_kernel(const InArgs A, con
 #pragma unroll
                 for (int t = 0; t < K4; ++t) {                    // branch-free: quads past C against zero weights
                     if (P.dbg & 1) break;
+                    if (CT > 1 && t >= nk4) break;                // two channel tiles: no steps against zero weights
                     const f2 a2 = *reinterpret_cast<const f2 *>(ap + 4 * min(t, nk4 - 1));
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, wq[hh][2 * t], d, 0, 0, 0);
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, wq[hh][2 * t + 1], d, 0, 0, 0);
@@ -3231,11 +3232,12 @@ static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr,
     return group_rows(g, A);
 }
 // q = g W and d_W = g^T Z (+ column sums of g) from one pass over grad_out (inagg_bwdgf_kernel<.., false>):
-// any graph -- the kernel never looks at it --, up to 8 heads, rows of at most 8 float4, even C <= 32.
+// any graph -- the kernel never looks at it --, up to 8 heads, rows of at most 8 float4, even C <= 40
+// (two 32-channel tiles per head from 34 on; up to 40 two blocks' LDS tiles still fit a CU).
 // GATMI_FUSED bit 3.
 static bool fused_products_cover(const InGeo &g, int H, int C) {
     if ((option("GATMI_FUSED", 11) & 8) == 0) return false;
-    return g.G == 64 && H <= 8 && g.lph <= 8 && C <= 32 && C % 2 == 0;
+    return g.G == 64 && H <= 8 && g.lph <= 8 && C <= 40 && C % 2 == 0;
 }
 struct FusePlan {
     int grid, grid_fwd, ct, vw;
@@ -3311,6 +3313,8 @@ static int fused_bwd_launch(const FusePlan &f, const InGeo &g, const InArgs &A, 
     P.zs = g.HF + 4;                         // the q tile is read back as float4
     const int lpr = next_pow2(P.C / f.vw);   // lanes per row of one head's columns of grad_out
     P.lpr_log = ilog2(lpr < 2 ? 2 : lpr);
+    if (P.qout && f.ct == 2)
+        return f.vw == 4 ? fused_bwd_launch_t<2, 4, false>(f, A, P, st) : fused_bwd_launch_t<2, 2, false>(f, A, P, st);
     if (P.qout) return f.vw == 4 ? fused_bwd_launch_t<1, 4, false>(f, A, P, st) : fused_bwd_launch_t<1, 2, false>(f, A, P, st);
     return f.vw == 4 ? fused_bwd_launch_t<1, 4, true>(f, A, P, st) : fused_bwd_launch_t<1, 2, true>(f, A, P, st);
 }

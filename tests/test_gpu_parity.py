@@ -483,7 +483,7 @@ FUSED_SHAPES = [  # n, f, h, c, p
     (3001, 25, 8, 30, 0.0), (3001, 25, 8, 30, 0.425), (9, 25, 8, 30, 0.0), (31, 25, 8, 24, 0.3),
     (32, 25, 8, 32, 0.0), (33, 25, 8, 28, 0.2), (1000, 17, 6, 9, 0.3), (1777, 32, 5, 16, 0.0),
     (2048, 1, 7, 2, 0.0), (4101, 25, 8, 40, 0.425), (777, 29, 8, 33, 0.0), (1500, 16, 8, 64, 0.1),
-    (2500, 25, 8, 31, 0.0), (640, 20, 5, 1, 0.0),
+    (2500, 25, 8, 31, 0.0), (640, 20, 5, 1, 0.0), (1200, 25, 8, 36, 0.0), (900, 24, 6, 34, 0.2),
 ]
 
 
@@ -492,7 +492,7 @@ FUSED_SHAPES = [  # n, f, h, c, p
 @pytest.mark.parametrize("n,f,h,c,p", FUSED_SHAPES)
 def test_input_aggregation_fused_tiles(cuda, n, f, h, c, p, graph, fused):
     """The fused 32-row tiles of the row-per-group layout (inagg_fwdgf / inagg_bwdgf: 5..8 heads, rows
-    of at most 8 float4, no row cut into segments; the backward for even C <= 32, the forward up to
+    of at most 8 float4, no row cut into segments; the backward for even C <= 32 (its products-only form up to 40), the forward up to
     C = 64) with GATMI_FUSED = 15 (both passes whatever the size), 9 (forward, and in the backward the
     products q = g W and d_W = g^T Z from one pass over grad_out ahead of the separate edge kernel),
     1 (forward only) and 0 (the separate kernels they replace): node counts around the tile size, channel counts around the 32-wide MFMA
