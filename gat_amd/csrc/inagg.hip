@@ -3232,12 +3232,13 @@ static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr,
     return group_rows(g, A);
 }
 // q = g W and d_W = g^T Z (+ column sums of g) from one pass over grad_out (inagg_bwdgf_kernel<.., false>):
-// any graph -- the kernel never looks at it --, up to 8 heads, rows of at most 8 float4, even C <= 40
-// (two 32-channel tiles per head from 34 on; up to 40 two blocks' LDS tiles still fit a CU).
+// any graph -- the kernel never looks at it --, up to 8 heads, rows of at most 8 float4, C <= 40 (two
+// 32-channel tiles per head from 33 on; up to 40 two blocks' LDS tiles still fit a CU; odd C: grad_out
+// staged float by float -- without the edge pass in the kernel that costs no registers).
 // GATMI_FUSED bit 3.
 static bool fused_products_cover(const InGeo &g, int H, int C) {
     if ((option("GATMI_FUSED", 11) & 8) == 0) return false;
-    return g.G == 64 && H <= 8 && g.lph <= 8 && C <= 40 && C % 2 == 0;
+    return g.G == 64 && H <= 8 && g.lph <= 8 && C <= 40;
 }
 struct FusePlan {
     int grid, grid_fwd, ct, vw;
@@ -3314,8 +3315,11 @@ static int fused_bwd_launch(const FusePlan &f, const InGeo &g, const InArgs &A, 
     const int lpr = next_pow2(P.C / f.vw);   // lanes per row of one head's columns of grad_out
     P.lpr_log = ilog2(lpr < 2 ? 2 : lpr);
     if (P.qout && f.ct == 2)
-        return f.vw == 4 ? fused_bwd_launch_t<2, 4, false>(f, A, P, st) : fused_bwd_launch_t<2, 2, false>(f, A, P, st);
-    if (P.qout) return f.vw == 4 ? fused_bwd_launch_t<1, 4, false>(f, A, P, st) : fused_bwd_launch_t<1, 2, false>(f, A, P, st);
+        return f.vw == 4 ? fused_bwd_launch_t<2, 4, false>(f, A, P, st)
+                         : (f.vw == 2 ? fused_bwd_launch_t<2, 2, false>(f, A, P, st) : fused_bwd_launch_t<2, 1, false>(f, A, P, st));
+    if (P.qout)
+        return f.vw == 4 ? fused_bwd_launch_t<1, 4, false>(f, A, P, st)
+                         : (f.vw == 2 ? fused_bwd_launch_t<1, 2, false>(f, A, P, st) : fused_bwd_launch_t<1, 1, false>(f, A, P, st));
     return f.vw == 4 ? fused_bwd_launch_t<1, 4, true>(f, A, P, st) : fused_bwd_launch_t<1, 2, true>(f, A, P, st);
 }
 

@@ -492,7 +492,7 @@ FUSED_SHAPES = [  # n, f, h, c, p
 @pytest.mark.parametrize("n,f,h,c,p", FUSED_SHAPES)
 def test_input_aggregation_fused_tiles(cuda, n, f, h, c, p, graph, fused):
     """The fused 32-row tiles of the row-per-group layout (inagg_fwdgf / inagg_bwdgf: 5..8 heads, rows
-    of at most 8 float4, no row cut into segments; the backward for even C <= 32 (its products-only form up to 40), the forward up to
+    of at most 8 float4, no row cut into segments; the backward for even C <= 32 (its products-only form for every C up to 40), the forward up to
     C = 64) with GATMI_FUSED = 15 (both passes whatever the size), 9 (forward, and in the backward the
     products q = g W and d_W = g^T Z from one pass over grad_out ahead of the separate edge kernel),
     1 (forward only) and 0 (the separate kernels they replace): node counts around the tile size, channel counts around the 32-wide MFMA

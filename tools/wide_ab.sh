@@ -5,7 +5,7 @@ set -e
 out=gpurun_out/wide_ab.txt
 : > $out
 for g in runpy100k runpy1m; do
-  for c in 34 36 38 40; do
+  for c in ${WIDE_C:-34 36 38 40}; do
     for fz in 11 3; do
       echo "== $g C=$c GATMI_FUSED=$fz" >> $out
       GATMI_FUSED=$fz timeout -k 10 120 python tools/layer_bench.py --graph $g --f 25 --heads 8 --channels $c --steps 20 >> $out 2>&1
