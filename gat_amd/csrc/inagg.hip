@@ -3215,12 +3215,14 @@ static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
 // MFMA tiles.  GATMI_FUSED=0: the separate kernels (A/B runs, the tests of the fallbacks); 1 / 2:
 // only the forward / the backward fused.
 constexpr int kFuseMaxC = 64;
-constexpr int kFuseBwdMaxRows = 400000;
+constexpr int kFuseBwdMaxRows = 200000;
 static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr, int C, bool bf16_rows, int pass) {
     // GATMI_FUSED: bit 0 the forward, bit 1 the backward (they do not depend on each other), bit 2:
     // the backward whatever the size.  By default the backward is fused up to kFuseBwdMaxRows rows:
     // beyond, with every CU busy for long, the separate kernels' higher occupancy wins (runpy1m: 1.64
-    // against 1.52 ms; runpy100k: 0.19 against 0.24)
+    // against 1.52 ms; runpy100k: 0.19 against 0.24) -- and so does the products-only pass
+    // with the edge kernel it spares the Z rows (300 k rows: 0.765 against 0.803 ms a step; 100 k: 0.353
+    // against 0.344)
     const int mode = option("GATMI_FUSED", 11);
     if ((mode & pass) == 0 || bf16_rows || C > kFuseMaxC) return false;
     if (pass == 2 && !(mode & 4) && gr->num_dst > kFuseBwdMaxRows) return false;
