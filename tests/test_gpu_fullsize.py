@@ -168,6 +168,18 @@ def test_runpy_shaped_million_nodes(cuda):
     for name, u, v in zip(("weight", "att_src", "att_dst", "bias"), t, t2):
         # a logit within rounding of zero may take the other LeakyReLU slope
         assert float((u - v).abs().max()) <= 2e-3 * float(v.abs().max()), name
+    # The default at this size: fused forward tiles, q / d_W / S = <q, Z> from one pass over grad_out, the
+    # edge kernel without its Z rows.  Against the separate kernels of the same layout (0) and the fully
+    # fused backward (15) the logits are the same floats: agreement to re-association
+    for fused in (0, 15):
+        _lib.set_option("GATMI_FUSED", fused)
+        try:
+            o3, t3 = step(g1 + 2 * g2)
+        finally:
+            _lib.set_option("GATMI_FUSED", -1)
+        assert float((o1 - o3).abs().max()) <= 2e-5 * float(o1.abs().max()), fused
+        for name, u, v in zip(("weight", "att_src", "att_dst", "bias"), t, t3):
+            assert float((u - v).abs().max()) <= 3e-5 * float(v.abs().max()), (fused, name)
 
 
 def test_eight_heads_wide_rows_at_scale(cuda):
