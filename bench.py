@@ -345,8 +345,14 @@ def measure_layer(workload, args, dev, dtype=None):
             f"normalisation), one GAT layer {f}->{h}x{c}{' (hidden layer: d_x computed)' if hidden else ''}, "
             f"attention dropout {args.dropout} (train mode)")
     ran_bf16 = "proj16_fwd_gemm" in avg or "inagg_pack16" in avg or "inagg_table16" in avg
+    kb = kernel_bytes(n, ep, h, d, f, feat_bytes=2 if ran_bf16 else 4)
+    edge_after = kb.pop("inagg_bwd_edge_after_products")
+    if "inagg_q_dw_fused" in avg and h > 4 and ep <= 12 * n and not ran_bf16:
+        # the row-per-group edge kernel (5..8 heads, low degree) takes S from the products pass and
+        # leaves the Z rows alone (gat_amd/csrc/inagg.hip: gatmi_inagg_bwd)
+        kb["inagg_bwd_edge"] = edge_after
     res = dict(nodes=n, edges=ep, f=f, h=h, c=c, avg=avg, dtype="bf16" if ran_bf16 else "f32",
-               kb=kernel_bytes(n, ep, h, d, f, feat_bytes=2 if ran_bf16 else 4),
+               kb=kb,
                ms_per_step=elapsed / args.steps * 1e3, layout_s=t_layout, text=text, graph_ms=graph_ms)
     del conv, x, go, layout, ei
     from gat_amd.graph import clear_graph_cache

@@ -89,4 +89,8 @@ def kernel_bytes(n, e, h, d, f, feat_bytes=4):
         # the backward reads the grad_out row (4 D) and Z once, q never exists in HBM
         "inagg_fwd_fused": e * (rowb + 4) + n * (4 + 4 * h + 4 * h * fp + 4 * h + 4 * d),
         "inagg_bwd_fused": e * (rowb + 4) + n * (4 + 4 * fs + 4 * d + 4 * h * fp + 8 * h),
+        # beyond 200 k rows the backward's products run as one pass over grad_out: reads the grad_out row
+        # and Z, writes q and S = <q, Z> per head; the edge kernel after it reads q and S, not Z
+        "inagg_q_dw_fused": n * (4 * d + 8 * h * fp + 4 * h),
+        "inagg_bwd_edge_after_products": e * (rowb + 4) + n * (4 + 4 * fs + 4 * h * fp + 12 * h),
     }
