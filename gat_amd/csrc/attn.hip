@@ -47,6 +47,10 @@ struct RowArgs {
                                       // instead of out / lse (NULL: the whole table is here)
     // backward edge pass (transposed CSR; hp = padded grad_out there)
     const void *hself;     // [N, Dp] projected features (row-local), same element type as hp
+    int hp_row;            // floats per row of hp: Dp, or H*C when g_compact
+    int g_compact;         // f32, C % 4 != 0, C > 4: hp is grad_out itself (rows of H*C floats, heads not padded).
+                           // A lane's four channels start at head*C + 4*sub; the last lane of a head loads the
+                           // head's last four channels instead and shifts (nothing is read outside the row)
     const float *nodeinfo; // [N, H, 4] (a_dst, lse, S, 0)
     float *du_t;           // [E', H] d_u in transposed-CSR order
     float *dhp;            // [N, Dp]
@@ -391,7 +395,17 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
     }
 }
 
-template <int LPH2_T, int G, int T, class RAW>
+// (v[sh], v[sh + 1], ..) with zeros behind: sh = 0 keeps v, sh = 4 clears it
+__device__ __forceinline__ float4 shift_out4(const float4 v, int sh) {
+    float4 r;
+    r.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : (sh == 3 ? v.w : 0.f)));
+    r.y = sh == 0 ? v.y : (sh == 1 ? v.z : (sh == 2 ? v.w : 0.f));
+    r.z = sh == 0 ? v.z : (sh == 1 ? v.w : 0.f);
+    r.w = sh == 0 ? v.w : 0.f;
+    return r;
+}
+
+template <int LPH2_T, int G, int T, class RAW, bool GC = false>
 __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
     const KeepSel ks = keep_sel(A.mask_mode, A.mask, A.seed);
 #ifndef GATMI_U16
@@ -403,6 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
     float4 att[T], hj[T], acc[T];
     float asj[T], das[T];
     unsigned offb[T], hbit[T], noff[T];
+    int gsh[T];                                                   // GC: elements the lane's load is shifted by
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         att[t] = ldc(A.att_src + S.coff[t], S.nval[t], vec_ok);
@@ -412,6 +427,11 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
         acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         das[t] = 0.f;
         offb[t] = (unsigned)S.poff[t] * 4u;
+        gsh[t] = 0;
+        if constexpr (GC) {                                       // idle lanes: the row's first bytes, all shifted out
+            gsh[t] = 4 - S.nval[t];
+            offb[t] = S.nval[t] ? (unsigned)(S.coff[t] - gsh[t]) * 4u : 0u;
+        }
         noff[t] = (unsigned)S.head[t] * 16u;
         hbit[t] = 1u << S.head[t];
     }
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
                 const int i = group_bcast<G>(ci, min(k0 + u, n - 1), gbase);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    v[u][t] = ld_slot<G, RAW>(A.hp, i, A.Dp, offb[t]);
+                    v[u][t] = ld_slot<G, RAW>(A.hp, i, A.hp_row, offb[t]);
                     q[u][t] = ld4_row<G>(A.nodeinfo, i, A.H * 4, noff[t]);
                 }
             }
@@ -437,7 +457,10 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int t = 0; t < T; ++t) v[u][t] = widen(raw[u][t]);
+                for (int t = 0; t < T; ++t) {
+                    v[u][t] = widen(raw[u][t]);
+                    if constexpr (GC) v[u][t] = shift_out4(v[u][t], gsh[t]);
+                }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool live = k0 + u < n;
@@ -857,6 +880,8 @@ static void launch_kind(Kind k, const RowArgs &A, int grid, hipStream_t st) {
     }
     if (k == FWD)
         hipLaunchKernelGGL((attn_fwd_kernel<LPH2_T, G, T, float4>), dim3(grid), dim3(256), 0, st, A);
+    else if (A.g_compact)     // its own instantiation: the shifts cost the padded-row kernel a wave of occupancy
+        hipLaunchKernelGGL((attn_bwd_edge_kernel<LPH2_T, G, T, float4, true>), dim3(grid), dim3(256), 0, st, A);
     else
         hipLaunchKernelGGL((attn_bwd_edge_kernel<LPH2_T, G, T, float4>), dim3(grid), dim3(256), 0, st, A);
 }
@@ -925,6 +950,7 @@ static void fill_common(RowArgs &A, const gatmi_attn &a, const Geometry &g) {
     A.mask = a.mask;
     A.seed = a.seed;
     A.hp = a.hp;
+    A.hp_row = g.Dp;
     A.a_dst = a.a_dst;
     A.att_src = a.att_src;
     A.att_dst = a.att_dst;
@@ -1095,6 +1121,18 @@ struct BwdWs {
     bf16x4 *g16;
     size_t bytes;
 };
+// C % 4 != 0 in f32: the edge pass gathers grad_out rows as they are (RowArgs::g_compact) instead of a
+// head-padded copy.  The copy is a third of the prep kernel's bytes (run.py's conv2, 8 x 30 at 10^6 nodes
+// and 6 edges a row: prep 0.78 -> 0.55 ms), but rows that are no multiple of a line cost the gather half
+// a line more per edge (edge pass 1.80 -> 1.92 ms): a gain up to about 12 edges a row, hence the default
+// for graphs of at most 8 -- the reference's 5-neighbour graphs.  GATMI_GCOMPACT=0: always the padded
+// copy, 2: never.
+static bool gather_compact(const gatmi_graph *g, int C) {
+    const int mode = option("GATMI_GCOMPACT", 1);
+    if ((C & 3) == 0 || C <= 4 || mode == 0) return false;
+    return mode == 2 || (long long)g->num_edges <= 8ll * g->num_dst;
+}
+
 BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo, void *ws,
                 bool feat_bf16) {
     Carver cv(ws);
@@ -1104,7 +1142,7 @@ BwdWs carve_bwd(const gatmi_graph *g, const gatmi_shape *s, const Geometry &geo,
     w.du_t = cv.take<float>((size_t)g->num_edges * H);
     // the grad_out rows the edge pass gathers: grad_out itself, a padded f32 copy (C % 4 != 0),
     // or -- bf16 feature tables -- a padded bf16 copy at half the bytes
-    w.gp = (!feat_bf16 && (s->channels & 3)) ? cv.take<float>(N * geo.Dp) : nullptr;
+    w.gp = (!feat_bf16 && (s->channels & 3) && !gather_compact(g, s->channels)) ? cv.take<float>(N * geo.Dp) : nullptr;
     w.g16 = feat_bf16 ? cv.take<bf16x4>(N * geo.Dp / 4) : nullptr;
     w.da_dst = cv.take<float>(N * H);
     w.da_src = cv.take<float>(NS * H);
@@ -1184,6 +1222,10 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
     RowArgs B;
     fill_common(B, *a, geo);
     B.hp = gpad;
+    if (!w.g16 && !w.gp && (C & 3)) {        // gather_compact: grad_out's own rows
+        B.hp_row = H * C;
+        B.g_compact = 1;
+    }
     B.hself = a->hp;
     B.nodeinfo = w.nodeinfo;
     B.rowptr = g->rowptr_t;

@@ -24,7 +24,7 @@ static const char *const kOptNames[] = {"GATMI_STREAM", "GATMI_BWD2", "GATMI_KRE
                                         "GATMI_EDGE8", "GATMI_GROUPROWS",
                                         "GATMI_GEMM_V2", "GATMI_QGROUP", "GATMI_OUTGROUP",
                                         "GATMI_KREG_WIDE", "GATMI_SPLIT3", "GATMI_DW16_ROWS", "GATMI_ADST_FUSED", "GATMI_BWD_HOIST",
-                                        "GATMI_KREG_DBUF", "GATMI_FUSED", "GATMI_FUSE_DBG", "GATMI_NARROW", "GATMI_NARROW_BLOCKS"};
+                                        "GATMI_KREG_DBUF", "GATMI_FUSED", "GATMI_FUSE_DBG", "GATMI_GCOMPACT", "GATMI_NARROW", "GATMI_NARROW_BLOCKS"};
 constexpr int kNumOpts = sizeof(kOptNames) / sizeof(kOptNames[0]);
 static int g_opt[kNumOpts];
 static const bool g_opt_init = [] {

@@ -588,6 +588,40 @@ def test_projection_gemm_variants(cuda, n, f, h, c, v2):
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("n,f,h,c", [(1000, 16, 8, 30), (700, 12, 3, 5), (513, 20, 3, 33), (300, 8, 16, 7),
+                                     (400, 8, 2, 130), (900, 9, 1, 6), (257, 8, 5, 9), (600, 8, 4, 63),
+                                     (350, 8, 7, 29), (64, 4, 2, 3)])
+def test_backward_gathers_grad_out_rows_as_they_are(cuda, n, f, h, c, p):
+    """Projected-row backward with C % 4 != 0: the edge pass gathers grad_out's own rows (heads not
+    padded to float4; the last lane of a head loads the head's last four channels and shifts) instead
+    of a head-padded copy written by the prep kernel (GATMI_GCOMPACT=0, C < 5, and by default graphs of
+    more than 8 edges a row).  Every lane layout
+    of the kernel (full-wave rows, 2 and 4 tiles per row, narrow rows of 8 / 16 / 32 lanes), odd and
+    even C, one head; both forms against the oracle and bit-equal to each other (same values, same
+    order)."""
+    from gat_amd import _lib, synth
+    ei = synth.powerlaw_graph(n, 7 * n, 300, seed=n)
+    inputs = cases.layer_inputs(n, f, h, c, seed=n + 5)
+    x, w, a_s, a_d, b, go = inputs
+    mask = cases.keep_mask(O.build_csr(ei, n).num_edges, h, p, seed=2) if p > 0 else None
+    ref_out, ref_g = O.gatconv_grads_autograd(x, ei, w, a_s, a_d, b, h, c, go, dropout=p, mask=mask,
+                                              training=p > 0)
+    summand = float(go.abs().max() * (x @ w.t()).abs().max())
+    res = {}
+    for mode in (2, 0):                                  # 2: whatever the degree (the default asks for <= 8 edges a row)
+        _lib.set_option("GATMI_GCOMPACT", mode)
+        try:
+            res[mode] = run_layer(cuda, ei, n, f, h, c, p, mask, 512, inputs)
+        finally:
+            _lib.set_option("GATMI_GCOMPACT", -1)
+    out, g = res[2]
+    close(out, ref_out, "out")
+    for k in g:
+        close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+        assert torch.equal(g[k], res[0][1][k]), k
+
+
 @pytest.mark.parametrize("grouped", [1, 0], ids=["head_groups", "per_head"])
 @pytest.mark.parametrize("n,f,h,c", [(4101, 25, 8, 30), (4200, 20, 4, 15), (4300, 30, 6, 10), (4150, 25, 3, 30)])
 def test_input_aggregation_unaligned_channel_rows(cuda, n, f, h, c, grouped):
