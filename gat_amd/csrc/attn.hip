@@ -275,17 +275,47 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(
 //   colsum    d_h[i] += d_a_dst[i] att_dst (row-local fix-up) fused with the parameter
 //             column sums.
 // ---------------------------------------------------------------------------------
+// (v[sh], v[sh + 1], ..) with zeros behind: sh = 0 keeps v, sh = 4 clears it
+__device__ __forceinline__ float4 shift_out4(const float4 v, int sh) {
+    float4 r;
+    r.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : (sh == 3 ? v.w : 0.f)));
+    r.y = sh == 0 ? v.y : (sh == 1 ? v.z : (sh == 2 ? v.w : 0.f));
+    r.z = sh == 0 ? v.z : (sh == 1 ? v.w : 0.f);
+    r.w = sh == 0 ? v.w : 0.f;
+    return r;
+}
+
+// a float4 at any 4-byte boundary (global loads need no more)
+__device__ __forceinline__ float4 ld4_unaligned(const float *p) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u r = *reinterpret_cast<const f4u *>(p);
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // Fast form of bwd_prep_kernel for C % 4 == 0 with power-of-two lanes per head and slots per
 // row (compact == padded layout): the tables are streamed as flat float4 arrays, 4 in flight
 // per thread, the per-head dot is a shuffle butterfly -- no LDS, no barrier in the loop.
+// COMPACT: C % 4 != 0, C > 4, no padded copy wanted (gather_compact): the same loop over rows of H*C
+// floats, a lane's four channels by one unaligned float4 load (the head's last lane: the last four
+// channels, shifted down -- attn_bwd_edge_kernel<.., GC = true> reads grad_out the same way).
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
     const float *gout, const float *outc, const float *bias, const float *a_dst, const float *lse,
-    long long nq /* float4 count = N*Dp/4 */, int H, int lph_log, int nslot, float4 *nodeinfo,
+    long long nq /* float4 count = N*Dp/4 */, int H, int C, int lph_log, int nslot, float4 *nodeinfo,
     float *gsum_partial, bf16x4 *g16 /* NULL, or the bf16 copy the edge pass gathers */) {
     const int lph = 1 << lph_log;
     const long long stride = (long long)gridDim.x * 256;   // multiple of nslot
     const int slot = threadIdx.x & (nslot - 1);
-    const float4 b4 = bias ? ld4(bias + slot * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int sh = 0, coff = slot * 4, nslot_log = 0;
+    if constexpr (COMPACT) {
+        const int head = slot >> lph_log, sub = slot & (lph - 1);
+        sh = 4 - min(C - 4 * sub, 4);                       // sub < lph = ceil(C / 4): 1..4 channels are real
+        coff = head * C + 4 * sub - sh;
+        nslot_log = 31 - __builtin_clz(nslot);
+    }
+    (void)nslot_log;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = COMPACT ? shift_out4(ld4_unaligned(bias + coff), sh) : ld4(bias + slot * 4);
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int UN = 8;
     for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 - threadIdx.x % 64 < nq;
@@ -295,12 +325,23 @@ __global__ __launch_bounds__(256) void bwd_prep_flat_kernel(
         for (int u = 0; u < UN; ++u) {
             const long long q = q0 + u * stride;
             const bool on = q < nq;
-            g4[u] = on ? ld4(gout + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            o4[u] = on ? ld4(outc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (COMPACT) {
+                const size_t at = (size_t)(on ? q >> nslot_log : 0) * (size_t)(H * C) + coff;
+                g4[u] = ld4_unaligned(gout + at);
+                o4[u] = ld4_unaligned(outc + at);
+            } else {
+                g4[u] = on ? ld4(gout + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                o4[u] = on ? ld4(outc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const long long q = q0 + u * stride;
+            if constexpr (COMPACT) {
+                const bool on = q < nq;
+                g4[u] = on ? shift_out4(g4[u], sh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                o4[u] = on ? shift_out4(o4[u], sh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             float4 o = o4[u];
             o.x -= b4.x; o.y -= b4.y; o.z -= b4.z; o.w -= b4.w;
             gsum.x += g4[u].x; gsum.y += g4[u].y; gsum.z += g4[u].z; gsum.w += g4[u].w;
@@ -393,16 +434,6 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
         }
         st4(gsum_partial + (size_t)blockIdx.x * Dp + slot * 4, s4);
     }
-}
-
-// (v[sh], v[sh + 1], ..) with zeros behind: sh = 0 keeps v, sh = 4 clears it
-__device__ __forceinline__ float4 shift_out4(const float4 v, int sh) {
-    float4 r;
-    r.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : (sh == 3 ? v.w : 0.f)));
-    r.y = sh == 0 ? v.y : (sh == 1 ? v.z : (sh == 2 ? v.w : 0.f));
-    r.z = sh == 0 ? v.z : (sh == 1 ? v.w : 0.f);
-    r.w = sh == 0 ? v.w : 0.f;
-    return r;
 }
 
 template <int LPH2_T, int G, int T, class RAW, bool GC = false>
@@ -1123,7 +1154,7 @@ struct BwdWs {
 };
 // C % 4 != 0 in f32: the edge pass gathers grad_out rows as they are (RowArgs::g_compact) instead of a
 // head-padded copy.  The copy is a third of the prep kernel's bytes (run.py's conv2, 8 x 30 at 10^6 nodes
-// and 6 edges a row: prep 0.78 -> 0.55 ms), but rows that are no multiple of a line cost the gather half
+// and 6 edges a row: prep 0.78 -> 0.47 ms), but rows that are no multiple of a line cost the gather half
 // a line more per edge (edge pass 1.80 -> 1.92 ms): a gain up to about 12 edges a row, hence the default
 // for graphs of at most 8 -- the reference's 5-neighbour graphs.  GATMI_GCOMPACT=0: always the padded
 // copy, 2: never.
@@ -1201,13 +1232,21 @@ extern "C" int gatmi_attn_bwd(const gatmi_graph *g, const gatmi_attn *a, const f
 
     {
         ProfScope ps("attn_bwd_prep", st);
-        const bool flat = (C & 3) == 0 && geo.lph == geo.lph2 && geo.lph <= 64 &&
+        const bool pow2 = geo.lph == geo.lph2 && geo.lph <= 64 &&
                           ((geo.Dp / 4) & (geo.Dp / 4 - 1)) == 0 && geo.Dp / 4 <= 256;
+        const bool flat = (C & 3) == 0 && pow2;
+        const bool flat_compact = (C & 3) != 0 && pow2 && !w.gp && !w.g16;   // gather_compact
         if (N > 0 && flat) {
-            hipLaunchKernelGGL(bwd_prep_flat_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out,
-                               out, a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H,
+            hipLaunchKernelGGL(bwd_prep_flat_kernel<false>, dim3(prep_blocks), dim3(256), 0, st, grad_out,
+                               out, a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H, C,
                                geo.lph2_log, geo.Dp / 4, reinterpret_cast<float4 *>(w.nodeinfo),
                                gsum_partial, w.g16);
+            GATMI_HIP(hipGetLastError());
+        } else if (N > 0 && flat_compact) {
+            hipLaunchKernelGGL(bwd_prep_flat_kernel<true>, dim3(prep_blocks), dim3(256), 0, st, grad_out,
+                               out, a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H, C,
+                               geo.lph2_log, geo.Dp / 4, reinterpret_cast<float4 *>(w.nodeinfo),
+                               gsum_partial, nullptr);
             GATMI_HIP(hipGetLastError());
         } else if (N > 0) {
             hipLaunchKernelGGL(bwd_prep_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
@@ -1541,8 +1580,8 @@ extern "C" int gatmi_attn_bwd_begin(const gatmi_attn *a, int max_chunks, const f
     const bool flat = (C & 3) == 0 && geo.lph == geo.lph2 && geo.lph <= 64 &&
                       ((geo.Dp / 4) & (geo.Dp / 4 - 1)) == 0 && geo.Dp / 4 <= 256;
     if (flat)
-        hipLaunchKernelGGL(bwd_prep_flat_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
-                           a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H, geo.lph2_log,
+        hipLaunchKernelGGL(bwd_prep_flat_kernel<false>, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,
+                           a->bias, a->a_dst, lse, (long long)N * (geo.Dp / 4), H, C, geo.lph2_log,
                            geo.Dp / 4, reinterpret_cast<float4 *>(w.nodeinfo), w.gsum_partial, w.g16);
     else
         hipLaunchKernelGGL(bwd_prep_kernel, dim3(prep_blocks), dim3(256), 0, st, grad_out, out,

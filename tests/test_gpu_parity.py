@@ -598,8 +598,8 @@ def test_backward_gathers_grad_out_rows_as_they_are(cuda, n, f, h, c, p):
     of a head-padded copy written by the prep kernel (GATMI_GCOMPACT=0, C < 5, and by default graphs of
     more than 8 edges a row).  Every lane layout
     of the kernel (full-wave rows, 2 and 4 tiles per row, narrow rows of 8 / 16 / 32 lanes), odd and
-    even C, one head; both forms against the oracle and bit-equal to each other (same values, same
-    order)."""
+    even C, one head; both forms against the oracle, and bit-equal to each other where both run the same
+    prep kernel."""
     from gat_amd import _lib, synth
     ei = synth.powerlaw_graph(n, 7 * n, 300, seed=n)
     inputs = cases.layer_inputs(n, f, h, c, seed=n + 5)
@@ -619,7 +619,13 @@ def test_backward_gathers_grad_out_rows_as_they_are(cuda, n, f, h, c, p):
     close(out, ref_out, "out")
     for k in g:
         close(g[k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
-        assert torch.equal(g[k], res[0][1][k]), k
+        close(res[0][1][k], ref_g[k], "d_" + k, floor=summand if k.startswith("att") else 0.0)
+    # the edge pass sees the same values in the same order either way; S = <g, out - b> is summed by a
+    # butterfly where the streaming prep kernel runs (8 x 30: eight lanes a head) and in lane order otherwise
+    assert torch.equal(out, res[0][0])
+    if (c + 3) // 4 & ((c + 3) // 4 - 1):
+        for k in g:
+            assert torch.equal(g[k], res[0][1][k]), k
 
 
 @pytest.mark.parametrize("grouped", [1, 0], ids=["head_groups", "per_head"])
