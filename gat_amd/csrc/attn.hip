@@ -285,13 +285,6 @@ __device__ __forceinline__ float4 shift_out4(const float4 v, int sh) {
     return r;
 }
 
-// a float4 at any 4-byte boundary (global loads need no more)
-__device__ __forceinline__ float4 ld4_unaligned(const float *p) {
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    const f4u r = *reinterpret_cast<const f4u *>(p);
-    return make_float4(r[0], r[1], r[2], r[3]);
-}
-
 // Fast form of bwd_prep_kernel for C % 4 == 0 with power-of-two lanes per head and slots per
 // row (compact == padded layout): the tables are streamed as flat float4 arrays, 4 in flight
 // per thread, the per-head dot is a shuffle butterfly -- no LDS, no barrier in the loop.

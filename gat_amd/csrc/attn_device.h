@@ -68,12 +68,26 @@ __device__ __forceinline__ void st4(float *p, const float4 &v) {
     *reinterpret_cast<float4 *>(p) = v;
 }
 
+// a float4 at any 4-byte boundary (global loads and stores need no more)
+__device__ __forceinline__ float4 ld4_unaligned(const float *p) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u r = *reinterpret_cast<const f4u *>(p);
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+__device__ __forceinline__ void st4_unaligned(float *p, const float4 &v) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    *reinterpret_cast<f4u *>(p) = f4u{v.x, v.y, v.z, v.w};
+}
+
 // Load/store of up to 4 floats of a COMPACT [.., H*C] row (heads not 16-byte aligned
-// unless C % 4 == 0).  nval = number of real channels in this slot (0..4).
+// unless C % 4 == 0).  nval = number of real channels in this slot (0..4).  Whole slots of unaligned
+// heads move as one 16-byte access all the same (C = 30: seven lanes of a head; the eighth two floats).
 __device__ __forceinline__ float4 ldc(const float *p, int nval, bool vec_ok) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vec_ok) {
         if (nval) r = ld4(p);
+    } else if (nval == 4) {
+        r = ld4_unaligned(p);
     } else {
         if (nval > 0) r.x = p[0];
         if (nval > 1) r.y = p[1];
@@ -85,6 +99,8 @@ __device__ __forceinline__ float4 ldc(const float *p, int nval, bool vec_ok) {
 __device__ __forceinline__ void stc(float *p, const float4 &v, int nval, bool vec_ok) {
     if (vec_ok) {
         if (nval) st4(p, v);
+    } else if (nval == 4) {
+        st4_unaligned(p, v);
     } else {
         if (nval > 0) p[0] = v.x;
         if (nval > 1) p[1] = v.y;
