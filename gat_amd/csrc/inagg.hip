@@ -3322,6 +3322,7 @@ static int fused_bwd_launch(const FusePlan &f, const InGeo &g, const InArgs &A, 
     if (P.qout)
         return f.vw == 4 ? fused_bwd_launch_t<1, 4, false>(f, A, P, st)
                          : (f.vw == 2 ? fused_bwd_launch_t<1, 2, false>(f, A, P, st) : fused_bwd_launch_t<1, 1, false>(f, A, P, st));
+    GATMI_REQUIRE(f.ct == 1 && f.vw != 1, "the fused backward takes even C <= 32 (fused_covers), got %d", P.C);
     return f.vw == 4 ? fused_bwd_launch_t<1, 4, true>(f, A, P, st) : fused_bwd_launch_t<1, 2, true>(f, A, P, st);
 }
 
