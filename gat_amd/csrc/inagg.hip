@@ -1934,15 +1934,40 @@ __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const I
         ydl[h * 64 + lane] = zero4();
     }
     const int stride = gridDim.x * 32;
-    for (int it0 = (xcd_contiguous_block() * 4 + wv) * 8; it0 < A.n_items; it0 += stride) {
+    // The item of the next pass is fetched during this one, a level of its dependent loads at a time
+    // (item arrays -> row pointer -> col and keep bits of its first eight edges): four round trips a
+    // pass instead of six
+    struct Ahead { int row, beg, end, cj, kb; bool on; };
+    auto ahead_item = [&](int it0, Ahead &M) {
         const int it = it0 + g;
-        const bool on = it < A.n_items;
-        int row = 0, beg = 0, end = 0;
-        if (on) {
-            row = A.item_row[it];
-            beg = A.item_beg[it];
-            end = min(A.rowptr[row + 1], beg + A.seg_len);
+        M.on = it < A.n_items;
+        M.row = M.beg = M.end = M.cj = M.kb = 0;
+        if (M.on) {
+            M.row = A.item_row[it];
+            M.beg = A.item_beg[it];
         }
+    };
+    auto ahead_end = [&](Ahead &M) {
+        if (M.on) M.end = min(A.rowptr[M.row + 1], M.beg + A.seg_len);
+    };
+    auto ahead_cols = [&](Ahead &M) {
+        const int n = min(max(M.end - M.beg, 0), 8);
+        const int el = M.beg + min(p, max(n - 1, 0));
+        M.cj = n > 0 ? A.col[el] : 0;
+        M.kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+    };
+    Ahead N1;
+    {
+        const int first = (xcd_contiguous_block() * 4 + wv) * 8;
+        ahead_item(first, N1);
+        ahead_end(N1);
+        ahead_cols(N1);
+    }
+    for (int it0 = (xcd_contiguous_block() * 4 + wv) * 8; it0 < A.n_items; it0 += stride) {
+        const Ahead M = N1;
+        const bool on = M.on;
+        const int row = M.row, beg = M.beg, end = M.end;
+        ahead_item(it0 + stride, N1);
         f4 q4[8];
         float S;
         if (A.sin) {                                              // wave-uniform: S came with q from the products pass
@@ -1970,10 +1995,14 @@ __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const I
         for (int c = 0; c < nmax; c += 8) {
             const int n = min(max(end - beg - c, 0), 8);
             const int nw = min(nmax - c, 8);
-            const int el = beg + c + min(p, max(n - 1, 0));
-            const int cj = n > 0 ? A.col[el] : 0;
-            const int kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+            int cj = M.cj, kb = M.kb;
+            if (c > 0) {                                          // wave-uniform
+                const int el = beg + c + min(p, max(n - 1, 0));
+                cj = n > 0 ? A.col[el] : 0;
+                kb = n > 0 ? (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)el, A.H) : 0;
+            }
             for (int e0 = 0; e0 < nw; e0 += kBwdgE) {             // kBwdgE rows in flight
+                if (c == 0 && e0 == kBwdgE) ahead_end(N1);        // the next item's row has arrived by now
                 f4 v[kBwdgE];
                 float as[kBwdgE];
                 unsigned sb[kBwdgE];
@@ -2012,6 +2041,8 @@ __global__ __launch_bounds__(256, GATMI_BWDG_OCC) void inagg_bwdg_kernel(const I
         // d_wd += (sum of the row's d_u) * x_i
         {
             const f4 xi = (on && pok) ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 4) : zero4();
+            if (nmax <= kBwdgE) ahead_end(N1);                    // rows of at most kBwdgE edges all round: not yet asked for
+            ahead_cols(N1);
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 const float dh = bcast_head<3>(dad, h);
