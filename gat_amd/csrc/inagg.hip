@@ -3246,14 +3246,15 @@ static void edge8_launch(InKind k, const InArgs &A, int grid, hipStream_t st) {
 // MFMA tiles.  GATMI_FUSED=0: the separate kernels (A/B runs, the tests of the fallbacks); 1 / 2:
 // only the forward / the backward fused.
 constexpr int kFuseMaxC = 64;
-constexpr int kFuseBwdMaxRows = 200000;
+constexpr int kFuseBwdMaxRows = 65536;
 static bool fused_covers(const InGeo &g, const InArgs &A, const gatmi_graph *gr, int C, bool bf16_rows, int pass) {
     // GATMI_FUSED: bit 0 the forward, bit 1 the backward (they do not depend on each other), bit 2:
     // the backward whatever the size.  By default the backward is fused up to kFuseBwdMaxRows rows:
     // beyond, with every CU busy for long, the separate kernels' higher occupancy wins (runpy1m: 1.64
     // against 1.52 ms; runpy100k: 0.19 against 0.24) -- and so does the products-only pass
-    // with the edge kernel it spares the Z rows (300 k rows: 0.765 against 0.803 ms a step; 100 k: 0.353
-    // against 0.344)
+    // with the edge kernel it spares the Z rows, once that kernel fetched its next item ahead (100 k rows:
+    // kernels 0.199 against 0.207 ms, a step replayed as a HIP graph 0.296 against 0.303, eager 0.334
+    // against 0.330; 30 k rows: kernels 0.088 against 0.077)
     const int mode = option("GATMI_FUSED", 11);
     if ((mode & pass) == 0 || bf16_rows || C > kFuseMaxC) return false;
     if (pass == 2 && !(mode & 4) && gr->num_dst > kFuseBwdMaxRows) return false;
