@@ -790,11 +790,39 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
         if (half == 0) stv4(ydl + h * 128 + p * 4, zero4());
     }
     const int stride = gridDim.x * 4;
-    for (int it = xcd_contiguous_block() * 4 + wv; it < A.n_items; it += stride) {
-        const int row = __builtin_amdgcn_readfirstlane(A.item_row[it]);
-        const int beg = __builtin_amdgcn_readfirstlane(A.item_beg[it]);
-        int end = __builtin_amdgcn_readfirstlane(A.rowptr[row + 1]);
+    // Items two passes ahead (scalar loads: the wave index is a scalar, what is fetched ahead waits in
+    // scalar registers): during pass k the item arrays of pass k + 2 and the row pointer of pass k + 1
+    // are in flight, so a pass starts at its q / Z rows and col entries instead of two round trips earlier
+    int it = xcd_contiguous_block() * 4 + __builtin_amdgcn_readfirstlane(wv);
+    int i1_row = 0, i1_beg = 0, i1_end = 0, i2_row = 0, i2_beg = 0;
+    int i1_col = 0;                                               // col entry of this lane in the item's first chunk
+    auto first_cols = [&]() {
+        const int nn = min(64, min(i1_end, i1_beg + A.seg_len) - i1_beg);
+        if (nn > 0) i1_col = A.col[i1_beg + min(lane, nn - 1)];
+    };
+    if (it < A.n_items) {
+        i1_row = A.item_row[it];
+        i1_beg = A.item_beg[it];
+        i1_end = A.rowptr[i1_row + 1];
+        first_cols();
+    }
+    if (it + stride < A.n_items) {
+        i2_row = A.item_row[it + stride];
+        i2_beg = A.item_beg[it + stride];
+    }
+    for (; it < A.n_items; it += stride) {
+        const int row = __builtin_amdgcn_readfirstlane(i1_row);
+        const int beg = __builtin_amdgcn_readfirstlane(i1_beg);
+        int end = __builtin_amdgcn_readfirstlane(i1_end);
         end = min(end, beg + A.seg_len);
+        const int first_col = i1_col;
+        i1_row = i2_row;
+        i1_beg = i2_beg;
+        i1_end = it + stride < A.n_items ? A.rowptr[i1_row + 1] : 0;
+        if (it + 2 * stride < A.n_items) {
+            i2_row = A.item_row[it + 2 * stride];
+            i2_beg = A.item_beg[it + 2 * stride];
+        }
         f4 q4[4];
         float sv[4];
 #pragma unroll
@@ -813,7 +841,7 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
         for (int c = beg; c < end; c += 64) {
             const int n = min(64, end - c);
             const int cl = min(lane, n - 1);
-            const int cj = A.col[c + cl];
+            const int cj = c == beg ? first_col : A.col[c + cl];
             const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
             auto load = [&](f4(&v)[U], int k0) {
 #pragma unroll
@@ -870,6 +898,7 @@ __global__ __launch_bounds__(256, 4) void inagg_bwd3_kernel(const InArgs A) {
         }
         // d_wd += (sum of the row's d_u) * x_i: both halves hold partial sums of d_u
         {
+            if (it + stride < A.n_items) first_cols();           // the next item's row pointer has arrived
             const float dt = dad + __shfl_xor(dad, 32, 64);
             const f4 xi = pok ? ldv4(A.xs + (size_t)(row + A.dst_off) * A.Fs + p * 4) : zero4();
             const float d0 = dpp_mov<0x00>(dt), d1 = dpp_mov<0xAA>(dt), d2h = dpp_mov<0x55>(dt),
