@@ -41,6 +41,12 @@ template <int G> __device__ __forceinline__ int group_bcast(int v, int k, int gb
         return __shfl(v, gbase + k, 64);
 }
 
+// A load through the constant address space: the graph layout is never written while a kernel runs, and with
+// a scalar index this is a scalar load whatever the kernel stores elsewhere (as a plain global load the
+// compiler has to keep it a vector load once the loop holds a store that might alias)
+typedef const int __attribute__((address_space(4))) *layout_ptr;
+__device__ __forceinline__ int ld_layout(const int *p, int i) { return ((layout_ptr)(p))[i]; }
+
 template <int G> __device__ __forceinline__ int uniform(int v) {
     if constexpr (G == 64)
         return __builtin_amdgcn_readfirstlane(v);

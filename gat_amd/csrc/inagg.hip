@@ -772,12 +772,6 @@ __device__ __forceinline__ float quad_heads_sum(float v0, float v1, float v2, fl
 // pointer of pass k + 2 and its lane's col entry of the first chunk of pass k + 1; the wave index is a
 // scalar, so everything but the col entry is a scalar load and waits in scalar registers.
 // ---------------------------------------------------------------------------------
-// A load through the constant address space: the graph layout is never written while a kernel runs, and with
-// a scalar index this is a scalar load whatever the kernel stores elsewhere (as a plain global load the
-// compiler has to keep it a vector load once the loop holds a store that might alias)
-typedef const int __attribute__((address_space(4))) *layout_ptr;
-__device__ __forceinline__ int ld_layout(const int *p, int i) { return ((layout_ptr)(p))[i]; }
-
 struct ItemsAhead {
     int r0, b0, s0, e0, c0;   // pass k: row, first edge, slot, row pointer of row + 1, col entry
     int r1, b1, s1, e1;       // pass k + 1
