@@ -59,6 +59,35 @@ struct RowArgs {
     float *part_dh;        // [slots_t, Dp]
 };
 
+// The work-item loop of the row kernels.  An item's description is a chain of dependent loads (item
+// arrays -> row pointer -> col of its first chunk) ahead of the first gathered row.  The loop runs ahead:
+// at the top of pass k it asks for the item arrays of pass k + 3, the row pointer of pass k + 2 and the
+// col (and aux) entries of the first chunk of pass k + 1.  Full-wave rows (G == 64) index the arrays with
+// a scalar and read them through the constant address space, so what is fetched ahead waits in scalar
+// registers.
+#define GATMI_ITEM_ARRAYS(i_, r_, b_, s_)                                                 \
+    {                                                                                     \
+        r_ = 0;                                                                           \
+        b_ = 0;                                                                           \
+        s_ = -1;                                                                          \
+        if ((i_) < A.n_items) {                                                           \
+            r_ = ld_layout(A.item_row, (i_));                                             \
+            b_ = ld_layout(A.item_beg, (i_));                                             \
+            s_ = ld_layout(A.item_slot, (i_));                                            \
+        }                                                                                 \
+    }
+#define GATMI_ITEM_END(i_, r_) ((i_) < A.n_items ? ld_layout(A.rowptr, (r_) + 1) : 0)
+#define GATMI_ITEM_FIRST_COLS(i_, b_, e_, c_, x_)                                         \
+    {                                                                                     \
+        const int nb_ = (b_);                                                             \
+        const int nn_ = min(G, min((e_), nb_ + A.seg_len) - nb_);                         \
+        if ((i_) < A.n_items && nn_ > 0) {                                                \
+            const int el_ = nb_ + min(lig, nn_ - 1);                                      \
+            c_ = A.col[el_];                                                              \
+            if (A.aux) x_ = A.aux[el_];                                                   \
+        }                                                                                 \
+    }
+
 #define GATMI_ITEM_LOOP_BEGIN                                                             \
     const int lane = threadIdx.x & 63;                                                    \
     const int lig = lane & (G - 1);                                                       \
@@ -69,13 +98,36 @@ struct RowArgs {
     const bool vec_ok = (A.C & 3) == 0;                                                   \
     constexpr int GPB = 256 / G;                                                          \
     const int stride = gridDim.x * GPB;                                                   \
-    for (int it = xcd_contiguous_block() * GPB + (int)threadIdx.x / G; it < A.n_items;    \
-         it += stride) {                                                                  \
-        const int row = uniform<G>(A.item_row[it]);                                       \
-        const int beg = uniform<G>(A.item_beg[it]);                                       \
-        const int slot = uniform<G>(A.item_slot[it]);                                     \
-        int end = uniform<G>(A.rowptr[row + 1]);                                          \
-        end = min(end, beg + A.seg_len);
+    const int grp_ = G == 64 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)      \
+                             : (int)threadIdx.x / G;                                      \
+    int it = xcd_contiguous_block() * GPB + grp_;                                         \
+    int i0_row, i0_beg, i0_slot, i0_end, i0_col = 0, i0_aux = 0;                          \
+    int i1_row, i1_beg, i1_slot, i1_end, i2_row, i2_beg, i2_slot;                         \
+    GATMI_ITEM_ARRAYS(it, i0_row, i0_beg, i0_slot)                                        \
+    i0_end = GATMI_ITEM_END(it, i0_row);                                                  \
+    GATMI_ITEM_FIRST_COLS(it, i0_beg, i0_end, i0_col, i0_aux)                             \
+    GATMI_ITEM_ARRAYS(it + stride, i1_row, i1_beg, i1_slot)                               \
+    i1_end = GATMI_ITEM_END(it + stride, i1_row);                                         \
+    GATMI_ITEM_ARRAYS(it + 2 * stride, i2_row, i2_beg, i2_slot)                           \
+    for (; it < A.n_items; it += stride) {                                                \
+        const int row = uniform<G>(i0_row);                                               \
+        const int beg = uniform<G>(i0_beg);                                               \
+        const int slot = uniform<G>(i0_slot);                                             \
+        int end = uniform<G>(i0_end);                                                     \
+        end = min(end, beg + A.seg_len);                                                  \
+        const int first_col = i0_col, first_aux = i0_aux;                                 \
+        (void)first_col;                                                                  \
+        (void)first_aux;                                                                  \
+        i0_row = i1_row;                                                                  \
+        i0_beg = i1_beg;                                                                  \
+        i0_slot = i1_slot;                                                                \
+        i0_end = i1_end;                                                                  \
+        GATMI_ITEM_FIRST_COLS(it + stride, i0_beg, i0_end, i0_col, i0_aux)                \
+        i1_row = i2_row;                                                                  \
+        i1_beg = i2_beg;                                                                  \
+        i1_slot = i2_slot;                                                                \
+        i1_end = GATMI_ITEM_END(it + 2 * stride, i1_row);                                 \
+        GATMI_ITEM_ARRAYS(it + 3 * stride, i2_row, i2_beg, i2_slot)
 
 #define GATMI_ITEM_LOOP_END }
 
@@ -112,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RowArgs A) {
     for (int c = beg; c < end; c += G) {
         const int n = min(G, end - c);
         const int cl = min(lig, n - 1);
-        const int cj = A.col[c + cl];
+        const int cj = c == beg ? first_col : A.col[c + cl];
         const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr, (long long)c + cl, A.H);
         auto load = [&](RAW(&v)[U][T], int k0) {
 #pragma unroll
@@ -462,9 +514,9 @@ __global__ __launch_bounds__(256) void attn_bwd_edge_kernel(const RowArgs A) {
     for (int c = beg; c < end; c += G) {
         const int n = min(G, end - c);
         const int cl = min(lig, n - 1);
-        const int ci = A.col[c + cl];
+        const int ci = c == beg ? first_col : A.col[c + cl];
         const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr,
-                                      (long long)A.aux[c + cl], A.H);
+                                      (long long)(c == beg ? first_aux : A.aux[c + cl]), A.H);
         auto load = [&](RAW(&v)[U][T], float4(&q)[U][T], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -569,9 +621,9 @@ __global__ __launch_bounds__(256) void attn_bwd_edge2_kernel(const RowArgs A) {
     for (int c = beg; c < end; c += 64) {
         const int n = min(64, end - c);
         const int cl = min(lane, n - 1);
-        const int ci = A.col[c + cl];
+        const int ci = c == beg ? first_col : A.col[c + cl];
         const int kb = (int)keep_bits(ks.mode, A.mask, ks.seed, A.keep_thr,
-                                      (long long)A.aux[c + cl], A.H);
+                                      (long long)(c == beg ? first_aux : A.aux[c + cl]), A.H);
         auto load = [&](RAW(&v)[U], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
