@@ -3368,7 +3368,11 @@ static FusePlan fuse_plan(const InGeo &g, int N, int H, int C, int F) {
     f.P.F = F;
     f.P.N = N;
     f.P.ntiles = (N + 31) / 32;
-    f.P.dbg = option("GATMI_FUSE_DBG", 0);
+#ifdef GATMI_ABLATION                        // timing-only switches that skip phases of the fused backward (results
+    f.P.dbg = option("GATMI_FUSE_DBG", 0);   // are wrong): only in builds made for tools/fused_dbg.sh
+#else
+    f.P.dbg = 0;
+#endif
     f.P.zs = g.HF + 2;                       // forward (the backward sets its own): 2 mod 4
     f.P.cp4 = round_up4(C);
     f.P.gs = 2 * f.P.cp4 + 2;                // 2 mod 4

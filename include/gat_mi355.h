@@ -50,7 +50,7 @@ int gatmi_version(void);
  * (no counterpart in the reference).  name = one of GATMI_STREAM, GATMI_FWD3, GATMI_BWD3,
  * GATMI_BWD2, GATMI_EDGE8, GATMI_GROUPROWS, GATMI_GEMM_V2, GATMI_QGROUP, GATMI_OUTGROUP,
  * GATMI_KRES, GATMI_KREG, GATMI_KREG_TAIL, GATMI_KREG_WIDE, GATMI_DW_STREAM, GATMI_DW_TAIL, GATMI_SPLIT3,
- * GATMI_DW16_ROWS, GATMI_ADST_FUSED, GATMI_BWD_HOIST, GATMI_KREG_DBUF, GATMI_FUSED, GATMI_FUSE_DBG, GATMI_GCOMPACT,
+ * GATMI_DW16_ROWS, GATMI_ADST_FUSED, GATMI_BWD_HOIST, GATMI_KREG_DBUF, GATMI_FUSED, GATMI_GCOMPACT,
  * GATMI_NARROW
  * (what each selects: DESIGN.md section 5, "A/B switches"); value >= 0 sets it, value < 0 hands
  * the decision back to the environment variable of the same name. */

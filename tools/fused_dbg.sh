@@ -1,4 +1,6 @@
 #!/bin/bash
+# Ablation of the fused backward's phases (timing only: results are wrong).  Needs a library built with
+# -DGATMI_ABLATION (make -C gat_amd/csrc clean all EXTRA=-DGATMI_ABLATION); the tree's build ignores GATMI_FUSE_DBG.
 out=gpurun_out/fused_dbg.txt
 : > $out
 for d in 0 1 2 8 16 32; do
