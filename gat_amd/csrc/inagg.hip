@@ -3987,7 +3987,7 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, f.grid, 2 * geo.HF, geo.HF};
         SumJob j2{w.slab, w.slab_sum, f.grid, tot, tot};
         SumJob j3{w.gsum, d_bias ? w.slab_sum + tot : nullptr, f.grid, H * C, H * C};
-        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((tot + 15) / 16, 4), dim3(256), 0, st, j0, j1, j2, j3);
+        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((max(tot, geo.HF) + 15) / 16, 4), dim3(256), 0, st, j0, j1, j2, j3);   // the widest job: H C F, or H Fp when C F < Fp
         GATMI_HIP(hipGetLastError());
         const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
         hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab_sum, 1, H, C, F,
@@ -4070,19 +4070,13 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
         else if (A.n_items > 0 && bwd3_covers(geo, H)) prow = w.waves / 4;
         SumJob j0{w.part_y, w.dwsd, prow, 2 * geo.HF, geo.HF};
         SumJob j1{w.part_y + geo.HF, w.dwsd + geo.HF, prow, 2 * geo.HF, geo.HF};
-        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0,
-                           j1, j1);
-        GATMI_HIP(hipGetLastError());
-    }
-    {
-        // slab[split][h] = g[:, h, :]^T Z[:, h, :] over the split's rows
-        ProfScope ps("inagg_dw_gemm", st);
         if (k1) {
-            // the slabs and g sums of the pass above: one row-sum launch, then the closing kernel on single rows
+            // with the slabs and g sums of the products pass: ONE row-sum launch (as behind the fused backward),
+            // then the closing kernel on single rows
             const int tot = H * C * F;
             SumJob j2{w.slab, w.slab_sum, fk.grid, tot, tot};
             SumJob j3{w.gsum, d_bias ? w.slab_sum + tot : nullptr, fk.grid, H * C, H * C};
-            hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((tot + 15) / 16, 2), dim3(256), 0, st, j2, j3, j3);
+            hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((max(tot, geo.HF) + 15) / 16, 4), dim3(256), 0, st, j0, j1, j2, j3);   // the widest job: H C F, or H Fp when C F < Fp
             GATMI_HIP(hipGetLastError());
             const int blocks = (int)((tot + 63) / 64 > 2048 ? 2048 : (tot + 63) / 64);
             hipLaunchKernelGGL(inagg_finalize_kernel, dim3(blocks), dim3(256), 0, st, w.slab_sum, 1, H, C, F, geo.Fp,
@@ -4091,6 +4085,13 @@ extern "C" int gatmi_inagg_bwd(const gatmi_graph *g, const gatmi_inagg *a, const
             GATMI_HIP(hipGetLastError());
             return GATMI_OK;
         }
+        hipLaunchKernelGGL(inagg_sum_rows_kernel, dim3((geo.HF + 15) / 16, 2), dim3(256), 0, st, j0,
+                           j1, j1);
+        GATMI_HIP(hipGetLastError());
+    }
+    {
+        // slab[split][h] = g[:, h, :]^T Z[:, h, :] over the split's rows
+        ProfScope ps("inagg_dw_gemm", st);
         if (N > 0) {
             GemmDesc d{};
             d.a_kmajor = true; d.b_kmajor = true;
